@@ -1,0 +1,203 @@
+/*
+ * nos.h — C ABI of the MI355X (gfx950) Gauss-Newton normal-equation assembly path.
+ *
+ * This is the drop-in boundary for the one data-parallel hot path of
+ * ChanghyeonKim93/nonlinear_optimizer_for_slam: per-correspondence residual +
+ * analytic Jacobian + robust weight, reduced into the upper triangle of JᵀJ, Jᵀr and
+ * the robust cost.  Every entry point replaces one piece of the reference's CPU path;
+ * the reference location is cited next to each declaration (paths are relative to the
+ * reference checkout, `NO/` = nonlinear_optimizer/, `MDM/` =
+ * NO/mahalanobis_distance_minimizer/, `REM/` = NO/reprojection_error_minimizer/).
+ *
+ * Conventions
+ *   - plain C, no exceptions cross this boundary; every function returns a nos_status
+ *     (0 = NOS_OK) and never a torch / Eigen / STL type.
+ *   - rotation matrices are row-major double[9]; translations double[3].
+ *   - parameter order of gradient / Hessian is (t_x, t_y, t_z, w_x, w_y, w_z), the
+ *     order the reference's update step uses (MDM/..._analytic_simd.cc:86-87).
+ *   - NDT planes are ordered  px py pz  mx my mz  s00 s01 s02 s10 s11 s12 s20 s21 s22
+ *     (point, NDT mean, row-major sqrt-information) — the 15 scalars the analytic
+ *     solvers read from each 304-byte Correspondence (MDM/types.h:11-26,
+ *     MDM/..._analytic.cc:164-168); reprojection planes are  X Y Z  u v
+ *     (REM/types.h:25-28).
+ *   - results:  out28 = { H upper triangle row-major (21) | g (6) | cost (1) },
+ *               out10 = { H upper triangle row-major (6)  | g (3) | cost (1) }.
+ *     The same 28 / 10 numbers the reference returns in PartialResult
+ *     (MDM/mahalanobis_distance_minimizer.h:14-18).
+ *   - all N correspondences are processed (the single-thread scalar class's behaviour,
+ *     MDM/..._analytic.cc:98-100), no SIMD tail is dropped.
+ */
+#ifndef NOS_H_
+#define NOS_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NOS_NDT_PLANES 15
+#define NOS_REPROJ_PLANES 5
+#define NOS_NDT6_OUT 28
+#define NOS_NDT3_OUT 10
+#define NOS_REPROJ_OUT 28
+
+typedef enum nos_status {
+  NOS_OK = 0,
+  NOS_ERR_INVALID_ARGUMENT = 1,
+  NOS_ERR_NO_DEVICE = 2,     /* no HIP device / runtime not usable: there is NO CPU fallback */
+  NOS_ERR_HIP = 3,           /* a HIP runtime call failed; see nos_last_error() */
+  NOS_ERR_OUT_OF_MEMORY = 4,
+  NOS_ERR_WRONG_KIND = 5,    /* e.g. an NDT entry point given a reprojection dataset */
+  NOS_ERR_UNSUPPORTED = 6
+} nos_status;
+
+/* Storage / arithmetic type of a device-resident dataset.  NOS_F64 mirrors the scalar
+ * fp64 classes (MDM/..._analytic.cc), NOS_F32 mirrors the SIMD classes which cast to
+ * float at pack time (MDM/..._analytic_simd.cc:25-27).  Reductions are always fp64. */
+typedef enum nos_dtype { NOS_F64 = 0, NOS_F32 = 1 } nos_dtype;
+
+/* Device-side restatement of NO/loss_function.h (a host virtual cannot cross to the
+ * GPU).  kind NONE: rho = s, w = 1 (loss_function_ == nullptr branch,
+ * MDM/..._analytic.cc:44-48).  EXPONENTIAL(a = c1, b = c2): NO/loss_function.h:28-33.
+ * HUBER(a = threshold): NO/loss_function.h:57-66. */
+typedef enum nos_loss_kind {
+  NOS_LOSS_NONE = 0,
+  NOS_LOSS_EXPONENTIAL = 1,
+  NOS_LOSS_HUBER = 2
+} nos_loss_kind;
+
+typedef struct nos_loss {
+  int32_t kind; /* nos_loss_kind */
+  int32_t reserved;
+  double a; /* c1 (exponential) | threshold (huber) */
+  double b; /* c2 (exponential) */
+} nos_loss;
+
+typedef struct nos_ctx nos_ctx;
+typedef struct nos_dataset nos_dataset;
+
+/* ---- context ------------------------------------------------------------------
+ * Replaces MultiThreadExecutor (NO/multi_thread_executor.h:51-73): instead of a pool
+ * of pinned threads the context owns, per listed device, one HIP stream, a block-partial
+ * workspace and a pinned result slot.  One process per GPU passes n_devices = 1 and
+ * all-reduces the 28 scalars with RCCL itself (see nos_*_accumulate_async); listing
+ * several devices gives the single-process fan-out the reference's thread pool had
+ * (correspondences are split into contiguous ranges, partials are summed on the
+ * caller in device order — MDM/..._analytic_simd.cc:55-76).
+ * The same device may be listed more than once (useful for testing the sharded path
+ * on a one-GPU box). */
+int nos_ctx_create(const int* device_ids, int n_devices, nos_ctx** out_ctx);
+int nos_ctx_destroy(nos_ctx* ctx);
+int nos_ctx_num_devices(const nos_ctx* ctx);
+/* Make shard `shard`'s launches go to an externally owned hipStream_t (e.g. the
+ * stream torch uses), so that collectives enqueued by the caller order after them.
+ * Passing NULL restores the context's own stream. */
+int nos_ctx_set_stream(nos_ctx* ctx, int shard, void* hip_stream);
+/* Block until all work enqueued on the context's streams has finished. */
+int nos_ctx_synchronize(nos_ctx* ctx);
+
+/* ---- datasets ------------------------------------------------------------------
+ * Replaces the per-Solve AoS→SoA pack (SOAData, MDM/..._analytic_simd.h:15-19 and
+ * .cc:19-28; AlignedBufferVarious, MDM/..._analytic_simd_various.h:14-44; AlignedBuffer,
+ * REM/..._analytic_simd.h:15-35).  The handle owns device memory in the library's
+ * tiled SoA layout; the caller keeps ownership of the host arrays (they are copied). */
+int nos_ndt_dataset_create(nos_ctx* ctx, size_t n, const double* const planes[NOS_NDT_PLANES],
+                           int dtype, nos_dataset** out_ds);
+int nos_reproj_dataset_create(nos_ctx* ctx, size_t n,
+                              const double* const planes[NOS_REPROJ_PLANES], int dtype,
+                              nos_dataset** out_ds);
+/* Same, from planes that already live in device memory of the context's FIRST device
+ * (element type given by src_dtype, planes contiguous, length n each).  The data is
+ * re-tiled on the device; the source planes are not referenced afterwards.
+ * Only valid for single-device contexts. */
+int nos_ndt_dataset_create_from_device(nos_ctx* ctx, size_t n,
+                                       const void* const d_planes[NOS_NDT_PLANES],
+                                       int src_dtype, int dtype, nos_dataset** out_ds);
+int nos_reproj_dataset_create_from_device(nos_ctx* ctx, size_t n,
+                                          const void* const d_planes[NOS_REPROJ_PLANES],
+                                          int src_dtype, int dtype, nos_dataset** out_ds);
+/* Ingest the reference's array-of-structures records directly: `records` points at n
+ * host records of `stride_bytes` each; the 15 (or 5) doubles are found at the given
+ * byte offsets inside a record (for the reference's 304-byte Correspondence:
+ * point @0, ndt.mean @128, ndt.sqrt_information @224 column-major — Eigen default —
+ * see INTEGRATION.md).  Records are staged through pinned memory and unpacked on the
+ * device (K6 in SURVEY.md §2.2). */
+int nos_ndt_dataset_create_from_records(nos_ctx* ctx, size_t n, const void* records,
+                                        size_t stride_bytes,
+                                        const size_t field_offsets[NOS_NDT_PLANES], int dtype,
+                                        nos_dataset** out_ds);
+int nos_reproj_dataset_create_from_records(nos_ctx* ctx, size_t n, const void* records,
+                                           size_t stride_bytes,
+                                           const size_t field_offsets[NOS_REPROJ_PLANES],
+                                           int dtype, nos_dataset** out_ds);
+int nos_dataset_destroy(nos_dataset* ds);
+size_t nos_dataset_size(const nos_dataset* ds);
+int nos_dataset_dtype(const nos_dataset* ds);
+/* Algorithmic bytes one accumulate pass streams from HBM for this dataset
+ * (n × planes × sizeof(element)); the figure roofline numbers are quoted against. */
+size_t nos_dataset_stream_bytes(const nos_dataset* ds);
+
+/* ---- the hot path -------------------------------------------------------------
+ * nos_ndt6_accumulate replaces
+ *   MahalanobisDistanceMinimizerAnalyticSIMD::ComputeCostAndDerivatives
+ *     (MDM/..._analytic_simd.cc:113-177) and its scalar twin
+ *   MahalanobisDistanceMinimizerAnalytic::ComputeCostAndDerivatives
+ *     (MDM/..._analytic.cc:12-52, 159-218)
+ * plus the thread fan-out / partial sum around them (MDM/..._analytic_simd.cc:55-76).
+ * Blocking; out28 is host memory. */
+int nos_ndt6_accumulate(nos_dataset* ds, const double R[9], const double t[3],
+                        const nos_loss* loss, double out28[NOS_NDT6_OUT]);
+/* nos_ndt3_accumulate replaces the planar (x, y, yaw) loops
+ *   MDM/..._analytic_3dof.cc:36-69,110-139 and MDM/..._analytic_3dof_simd.cc:85-158.
+ * R2 is the row-major 2×2 rotation, t2 the planar translation. */
+int nos_ndt3_accumulate(nos_dataset* ds, const double R2[4], const double t2[2],
+                        const nos_loss* loss, double out10[NOS_NDT3_OUT]);
+/* nos_reproj_accumulate replaces REM/..._analytic.cc:31-64,107-162 and the SIMD loop
+ * REM/..._analytic_simd.cc:55-138.  intr = {inv_fx, inv_fy, cx, cy}; points whose
+ * transformed depth is < min_depth contribute nothing (scalar class: 0.03,
+ * REM/..._analytic.cc:111,119-123). */
+int nos_reproj_accumulate(nos_dataset* ds, const double R[9], const double t[3],
+                          const double intr[4], const nos_loss* loss, double min_depth,
+                          double out28[NOS_REPROJ_OUT]);
+
+/* Asynchronous forms for one-process-per-GPU use: enqueue kernel + final reduce on
+ * the context's stream (single-device contexts only) and leave the 28 / 10 doubles
+ * in DEVICE memory at d_out, e.g. a torch tensor that the caller then hands to
+ * ncclAllReduce / torch.distributed.all_reduce on the same stream.  This is the
+ * reference's "sum the per-thread partials" step (MDM/..._analytic_simd.cc:70-75)
+ * moved onto RCCL.  No host synchronisation happens inside. */
+int nos_ndt6_accumulate_async(nos_dataset* ds, const double R[9], const double t[3],
+                              const nos_loss* loss, double* d_out28);
+int nos_ndt3_accumulate_async(nos_dataset* ds, const double R2[4], const double t2[2],
+                              const nos_loss* loss, double* d_out10);
+int nos_reproj_accumulate_async(nos_dataset* ds, const double R[9], const double t[3],
+                                const double intr[4], const nos_loss* loss, double min_depth,
+                                double* d_out28);
+
+/* ---- measurement / diagnostics ------------------------------------------------- */
+/* Launch geometry override (0 = library default).  tuning knob, not needed for use. */
+int nos_ctx_set_launch(nos_ctx* ctx, int blocks_per_cu, int reserved);
+/* Time `repeats` back-to-back assemble launches of shard 0 with HIP events recorded on
+ * the stream the kernels are launched on; returns the mean per-launch duration of the
+ * assemble kernel alone (kernel_ms) and of assemble + final reduce (total_ms). */
+int nos_ndt6_time_kernel(nos_dataset* ds, const double R[9], const double t[3],
+                         const nos_loss* loss, int repeats, double* kernel_ms,
+                         double* total_ms);
+int nos_reproj_time_kernel(nos_dataset* ds, const double R[9], const double t[3],
+                           const double intr[4], const nos_loss* loss, double min_depth,
+                           int repeats, double* kernel_ms, double* total_ms);
+int nos_ndt3_time_kernel(nos_dataset* ds, const double R2[4], const double t2[2],
+                         const nos_loss* loss, int repeats, double* kernel_ms,
+                         double* total_ms);
+const char* nos_status_string(int status);
+/* Thread-local description of the last failure in this thread ("" if none). */
+const char* nos_last_error(void);
+const char* nos_version(void);
+
+#ifdef __cplusplus
+} /* extern "C" */
+#endif
+
+#endif /* NOS_H_ */

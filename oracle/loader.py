@@ -1,0 +1,256 @@
+"""ctypes access to the CPU oracle — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py``
+may import this module (see oracle/nos_oracle.h).  It never touches the GPU.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_BUILD = os.path.join(_HERE, "build")
+
+c_double_p = ctypes.POINTER(ctypes.c_double)
+
+
+class OracleLoss(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int), ("a", ctypes.c_double), ("b", ctypes.c_double)]
+
+
+class OracleOptions(ctypes.Structure):
+    _fields_ = [
+        ("max_iterations", ctypes.c_int),
+        ("gradient_tolerance", ctypes.c_double),
+        ("parameter_tolerance", ctypes.c_double),
+        ("linear_solver", ctypes.c_int),
+    ]
+
+
+class OracleReport(ctypes.Structure):
+    _fields_ = [
+        ("iterations", ctypes.c_int),
+        ("printed_cost", ctypes.c_double),
+        ("last_cost", ctypes.c_double),
+        ("final_lambda", ctypes.c_double),
+    ]
+
+
+def build(force=False):
+    """Compile the oracle libraries with the committed Makefile (gcc only)."""
+    need = force or not all(
+        os.path.exists(os.path.join(_BUILD, f))
+        for f in ("libnos_oracle.so", "libnos_oracle_avx.so")
+    )
+    if need:
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+
+
+_lib = None
+_avx = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(os.path.join(_BUILD, "libnos_oracle.so"))
+        _lib.oracle_ndt6_accumulate.restype = None
+        _lib.oracle_ndt3_accumulate.restype = None
+        _lib.oracle_reproj_accumulate.restype = None
+    return _lib
+
+
+def avx():
+    global _avx
+    if _avx is None:
+        build()
+        _avx = ctypes.CDLL(os.path.join(_BUILD, "libnos_oracle_avx.so"))
+        _avx.oracle_avx_ndt6_accumulate.restype = ctypes.c_int
+    return _avx
+
+
+def _planes_arg(planes, count):
+    """planes: array [count, n] float64 C-contiguous → (ctypes array of row pointers, keepalive)."""
+    planes = np.ascontiguousarray(planes, dtype=np.float64)
+    assert planes.ndim == 2 and planes.shape[0] == count, planes.shape
+    arr = (c_double_p * count)()
+    for k in range(count):
+        arr[k] = planes[k].ctypes.data_as(c_double_p)
+    return arr, planes
+
+
+def _vec(x, n):
+    a = np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1))
+    assert a.size == n, (a.size, n)
+    return a
+
+
+def make_loss(loss):
+    """loss: None | ("exponential", c1, c2) | ("huber", th) | ("none",)."""
+    if loss is None or loss[0] == "none":
+        return OracleLoss(0, 0.0, 0.0)
+    if loss[0] == "exponential":
+        return OracleLoss(1, float(loss[1]), float(loss[2]))
+    if loss[0] == "huber":
+        return OracleLoss(2, float(loss[1]), 0.0)
+    raise ValueError(loss)
+
+
+def ndt6_accumulate(planes, R, t, loss=None):
+    arr, keep = _planes_arg(planes, 15)
+    R = _vec(R, 9)
+    t = _vec(t, 3)
+    out = np.zeros(28)
+    l = make_loss(loss)
+    lib().oracle_ndt6_accumulate(
+        ctypes.c_size_t(keep.shape[1]), arr, R.ctypes.data_as(c_double_p),
+        t.ctypes.data_as(c_double_p), ctypes.byref(l), out.ctypes.data_as(c_double_p))
+    return out
+
+
+def ndt6_accumulate_f32lanes(planes, R, t, loss=None, drop_tail=False):
+    arr, keep = _planes_arg(planes, 15)
+    R = _vec(R, 9)
+    t = _vec(t, 3)
+    out = np.zeros(28)
+    l = make_loss(loss)
+    lib().oracle_ndt6_accumulate_f32lanes(
+        ctypes.c_size_t(keep.shape[1]), arr, R.ctypes.data_as(c_double_p),
+        t.ctypes.data_as(c_double_p), ctypes.byref(l), ctypes.c_int(int(drop_tail)),
+        out.ctypes.data_as(c_double_p))
+    return out
+
+
+def ndt3_accumulate(planes, R2, t2, loss=None):
+    arr, keep = _planes_arg(planes, 15)
+    R2 = _vec(R2, 4)
+    t2 = _vec(t2, 2)
+    out = np.zeros(10)
+    l = make_loss(loss)
+    lib().oracle_ndt3_accumulate(
+        ctypes.c_size_t(keep.shape[1]), arr, R2.ctypes.data_as(c_double_p),
+        t2.ctypes.data_as(c_double_p), ctypes.byref(l), out.ctypes.data_as(c_double_p))
+    return out
+
+
+def reproj_accumulate(planes, R, t, intr, loss=None, min_depth=0.03):
+    arr, keep = _planes_arg(planes, 5)
+    R = _vec(R, 9)
+    t = _vec(t, 3)
+    intr = _vec(intr, 4)
+    out = np.zeros(28)
+    l = make_loss(loss)
+    lib().oracle_reproj_accumulate(
+        ctypes.c_size_t(keep.shape[1]), arr, R.ctypes.data_as(c_double_p),
+        t.ctypes.data_as(c_double_p), intr.ctypes.data_as(c_double_p), ctypes.byref(l),
+        ctypes.c_double(min_depth), out.ctypes.data_as(c_double_p))
+    return out
+
+
+def _options(max_iterations=40, gradient_tolerance=1e-6, parameter_tolerance=1e-6,
+             linear_solver=0):
+    return OracleOptions(int(max_iterations), float(gradient_tolerance),
+                         float(parameter_tolerance), int(linear_solver))
+
+
+def _solve_result(t, R, rep):
+    return {
+        "t": t.copy(), "R": R.reshape(3, 3).copy(), "iterations": rep.iterations,
+        "printed_cost": rep.printed_cost, "last_cost": rep.last_cost,
+        "final_lambda": rep.final_lambda,
+    }
+
+
+def ndt6_solve(planes, t0, R0, loss=None, **opt):
+    arr, keep = _planes_arg(planes, 15)
+    t = _vec(t0, 3).copy()
+    R = _vec(R0, 9).copy()
+    o = _options(**opt)
+    l = make_loss(loss)
+    rep = OracleReport()
+    lib().oracle_ndt6_solve(
+        ctypes.c_size_t(keep.shape[1]), arr, ctypes.byref(o), ctypes.byref(l),
+        t.ctypes.data_as(c_double_p), R.ctypes.data_as(c_double_p), ctypes.byref(rep))
+    return _solve_result(t, R, rep)
+
+
+def ndt3_solve(planes, t0, R0, loss=None, **opt):
+    arr, keep = _planes_arg(planes, 15)
+    t = _vec(t0, 3).copy()
+    R = _vec(R0, 9).copy()
+    o = _options(**opt)
+    l = make_loss(loss)
+    rep = OracleReport()
+    lib().oracle_ndt3_solve(
+        ctypes.c_size_t(keep.shape[1]), arr, ctypes.byref(o), ctypes.byref(l),
+        t.ctypes.data_as(c_double_p), R.ctypes.data_as(c_double_p), ctypes.byref(rep))
+    return _solve_result(t, R, rep)
+
+
+def reproj_solve(planes, intr, t0, R0, loss=None, min_depth=0.03, **opt):
+    arr, keep = _planes_arg(planes, 5)
+    intr = _vec(intr, 4)
+    t = _vec(t0, 3).copy()
+    R = _vec(R0, 9).copy()
+    o = _options(**opt)
+    l = make_loss(loss)
+    rep = OracleReport()
+    lib().oracle_reproj_solve(
+        ctypes.c_size_t(keep.shape[1]), arr, intr.ctypes.data_as(c_double_p), ctypes.byref(o),
+        ctypes.byref(l), ctypes.c_double(min_depth), t.ctypes.data_as(c_double_p),
+        R.ctypes.data_as(c_double_p), ctypes.byref(rep))
+    return _solve_result(t, R, rep)
+
+
+def lm_step6(out28, lam, linear_solver=0):
+    out28 = _vec(out28, 28)
+    step = np.zeros(6)
+    lib().oracle_lm_step6(out28.ctypes.data_as(c_double_p), ctypes.c_double(lam),
+                          ctypes.c_int(linear_solver), step.ctypes.data_as(c_double_p))
+    return step
+
+
+def lm_step3(out10, lam):
+    out10 = _vec(out10, 10)
+    step = np.zeros(3)
+    lib().oracle_lm_step3(out10.ctypes.data_as(c_double_p), ctypes.c_double(lam),
+                          step.ctypes.data_as(c_double_p))
+    return step
+
+
+def quat_from_matrix(R):
+    R = _vec(R, 9)
+    q = np.zeros(4)
+    lib().oracle_quat_from_matrix(R.ctypes.data_as(c_double_p), q.ctypes.data_as(c_double_p))
+    return q
+
+
+def quat_to_matrix(q):
+    q = _vec(q, 4)
+    R = np.zeros(9)
+    lib().oracle_quat_to_matrix(q.ctypes.data_as(c_double_p), R.ctypes.data_as(c_double_p))
+    return R.reshape(3, 3)
+
+
+def avx_ndt6_accumulate(planes_f32, R, t, loss=None, threads=1):
+    """AVX2/FMA fp32 baseline.  planes_f32: [15, n] float32, n multiple of 8 is processed
+    (floor(n/8)*8 like the reference)."""
+    p = np.ascontiguousarray(planes_f32, dtype=np.float32)
+    assert p.ndim == 2 and p.shape[0] == 15
+    fp = ctypes.POINTER(ctypes.c_float)
+    arr = (fp * 15)()
+    for k in range(15):
+        arr[k] = p[k].ctypes.data_as(fp)
+    R = _vec(R, 9)
+    t = _vec(t, 3)
+    out = np.zeros(28)
+    l = make_loss(loss)
+    rc = avx().oracle_avx_ndt6_accumulate(
+        ctypes.c_size_t(p.shape[1]), arr, R.ctypes.data_as(c_double_p),
+        t.ctypes.data_as(c_double_p), ctypes.byref(l), ctypes.c_int(threads),
+        out.ctypes.data_as(c_double_p))
+    if rc != 0:
+        raise RuntimeError("oracle_avx_ndt6_accumulate failed: %d" % rc)
+    return out
