@@ -177,8 +177,9 @@ int nos_reproj_accumulate_async(nos_dataset* ds, const double R[9], const double
                                 double* d_out28);
 
 /* ---- measurement / diagnostics ------------------------------------------------- */
-/* Launch geometry override (0 = library default).  tuning knob, not needed for use. */
-int nos_ctx_set_launch(nos_ctx* ctx, int blocks_per_cu, int reserved);
+/* Launch geometry override (0 = library default): blocks per CU of the assemble grid and
+ * the index of the compiled kernel geometry.  Tuning knob, not needed for normal use. */
+int nos_ctx_set_launch(nos_ctx* ctx, int blocks_per_cu, int variant);
 /* Time `repeats` back-to-back assemble launches of shard 0 with HIP events recorded on
  * the stream the kernels are launched on; returns the mean per-launch duration of the
  * assemble kernel alone (kernel_ms) and of assemble + final reduce (total_ms). */

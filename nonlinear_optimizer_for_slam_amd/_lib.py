@@ -1,0 +1,109 @@
+"""ctypes binding of libnos_hip.so (the C ABI in include/nos.h).
+
+The library is the product; this module only loads it.  If the shared object is missing or a
+HIP device is not usable, every call raises — there is no CPU fallback anywhere in the package.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_HIP = os.path.join(CSRC, "libnos_hip.so")
+LIB_HOST = os.path.join(CSRC, "libnos_host.so")
+
+c_double_p = ctypes.POINTER(ctypes.c_double)
+c_void_pp = ctypes.POINTER(ctypes.c_void_p)
+
+NOS_OK = 0
+NOS_F64 = 0
+NOS_F32 = 1
+NOS_LOSS_NONE = 0
+NOS_LOSS_EXPONENTIAL = 1
+NOS_LOSS_HUBER = 2
+
+# every symbol include/nos.h declares; tests check the library exports all of them
+C_ABI_SYMBOLS = (
+    "nos_ctx_create", "nos_ctx_destroy", "nos_ctx_num_devices", "nos_ctx_set_stream",
+    "nos_ctx_synchronize", "nos_ndt_dataset_create", "nos_reproj_dataset_create",
+    "nos_ndt_dataset_create_from_device", "nos_reproj_dataset_create_from_device",
+    "nos_ndt_dataset_create_from_records", "nos_reproj_dataset_create_from_records",
+    "nos_dataset_destroy", "nos_dataset_size", "nos_dataset_dtype", "nos_dataset_stream_bytes",
+    "nos_ndt6_accumulate", "nos_ndt3_accumulate", "nos_reproj_accumulate",
+    "nos_ndt6_accumulate_async", "nos_ndt3_accumulate_async", "nos_reproj_accumulate_async",
+    "nos_ctx_set_launch", "nos_ndt6_time_kernel", "nos_reproj_time_kernel",
+    "nos_ndt3_time_kernel", "nos_status_string", "nos_last_error", "nos_version",
+)
+
+
+class NosLoss(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("a", ctypes.c_double), ("b", ctypes.c_double)]
+
+
+class NosError(RuntimeError):
+    def __init__(self, status, where, detail):
+        super().__init__("%s failed: status %d (%s)" % (where, status, detail))
+        self.status = status
+
+
+_hip = None
+
+
+def hip_lib():
+    """Load libnos_hip.so; raises if it has not been built (no fallback)."""
+    global _hip
+    if _hip is None:
+        if not os.path.exists(LIB_HIP):
+            raise ImportError(
+                "libnos_hip.so is missing at %s — build it with `python __graft_entry__.py` "
+                "(hipcc --offload-arch=gfx950); this package has no CPU fallback." % LIB_HIP)
+        lib = ctypes.CDLL(LIB_HIP)
+        _declare(lib)
+        _hip = lib
+    return _hip
+
+
+def _declare(lib):
+    vp = ctypes.c_void_p
+    sz = ctypes.c_size_t
+    i = ctypes.c_int
+    dp = c_double_p
+    lp = ctypes.POINTER(NosLoss)
+    lib.nos_ctx_create.argtypes = [ctypes.POINTER(ctypes.c_int), i, c_void_pp]
+    lib.nos_ctx_destroy.argtypes = [vp]
+    lib.nos_ctx_num_devices.argtypes = [vp]
+    lib.nos_ctx_set_stream.argtypes = [vp, i, vp]
+    lib.nos_ctx_synchronize.argtypes = [vp]
+    lib.nos_ctx_set_launch.argtypes = [vp, i, i]
+    lib.nos_ndt_dataset_create.argtypes = [vp, sz, ctypes.POINTER(dp), i, c_void_pp]
+    lib.nos_reproj_dataset_create.argtypes = [vp, sz, ctypes.POINTER(dp), i, c_void_pp]
+    lib.nos_ndt_dataset_create_from_device.argtypes = [vp, sz, c_void_pp, i, i, c_void_pp]
+    lib.nos_reproj_dataset_create_from_device.argtypes = [vp, sz, c_void_pp, i, i, c_void_pp]
+    lib.nos_ndt_dataset_create_from_records.argtypes = [vp, sz, vp, sz, ctypes.POINTER(sz), i, c_void_pp]
+    lib.nos_reproj_dataset_create_from_records.argtypes = [vp, sz, vp, sz, ctypes.POINTER(sz), i, c_void_pp]
+    lib.nos_dataset_destroy.argtypes = [vp]
+    lib.nos_dataset_size.argtypes = [vp]
+    lib.nos_dataset_size.restype = sz
+    lib.nos_dataset_dtype.argtypes = [vp]
+    lib.nos_dataset_stream_bytes.argtypes = [vp]
+    lib.nos_dataset_stream_bytes.restype = sz
+    lib.nos_ndt6_accumulate.argtypes = [vp, dp, dp, lp, dp]
+    lib.nos_ndt3_accumulate.argtypes = [vp, dp, dp, lp, dp]
+    lib.nos_reproj_accumulate.argtypes = [vp, dp, dp, dp, lp, ctypes.c_double, dp]
+    lib.nos_ndt6_accumulate_async.argtypes = [vp, dp, dp, lp, vp]
+    lib.nos_ndt3_accumulate_async.argtypes = [vp, dp, dp, lp, vp]
+    lib.nos_reproj_accumulate_async.argtypes = [vp, dp, dp, dp, lp, ctypes.c_double, vp]
+    lib.nos_ndt6_time_kernel.argtypes = [vp, dp, dp, lp, i, dp, dp]
+    lib.nos_ndt3_time_kernel.argtypes = [vp, dp, dp, lp, i, dp, dp]
+    lib.nos_reproj_time_kernel.argtypes = [vp, dp, dp, dp, lp, ctypes.c_double, i, dp, dp]
+    lib.nos_status_string.argtypes = [i]
+    lib.nos_status_string.restype = ctypes.c_char_p
+    lib.nos_last_error.restype = ctypes.c_char_p
+    lib.nos_version.restype = ctypes.c_char_p
+
+
+def check(status, where):
+    if status != NOS_OK:
+        lib = hip_lib()
+        detail = "%s: %s" % (lib.nos_status_string(status).decode(), lib.nos_last_error().decode())
+        raise NosError(status, where, detail)

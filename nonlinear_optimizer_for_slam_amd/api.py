@@ -1,0 +1,258 @@
+"""Thin Python handles over the C ABI (include/nos.h): Context, NdtDataset, ReprojDataset.
+
+numpy arrays go in and out; torch is optional and only used for device-resident planes
+(`from_device_planes`) and for device-resident results (`*_async`), i.e. as plumbing for
+device memory, streams and torch.distributed — all arithmetic happens in libnos_hip.so.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import (NOS_F32, NOS_F64, NOS_LOSS_EXPONENTIAL, NOS_LOSS_HUBER, NOS_LOSS_NONE,
+                   NosLoss, c_double_p, c_void_pp, check, hip_lib)
+
+_DTYPES = {"f64": NOS_F64, "f32": NOS_F32, NOS_F64: NOS_F64, NOS_F32: NOS_F32}
+
+
+def make_loss(loss):
+    """None | ("none",) | ("exponential", c1, c2) | ("huber", threshold) → NosLoss.
+
+    Mirrors the constructors of the reference's loss_function.h (ExponentialLossFunction(c1, c2),
+    HuberLossFunction(threshold)); argument validation happens inside the C ABI.
+    """
+    if loss is None or loss[0] == "none":
+        return NosLoss(NOS_LOSS_NONE, 0, 0.0, 0.0)
+    if loss[0] == "exponential":
+        return NosLoss(NOS_LOSS_EXPONENTIAL, 0, float(loss[1]), float(loss[2]))
+    if loss[0] == "huber":
+        return NosLoss(NOS_LOSS_HUBER, 0, float(loss[1]), 0.0)
+    raise ValueError("unknown loss %r" % (loss,))
+
+
+def _dvec(x, n):
+    a = np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1))
+    if a.size != n:
+        raise ValueError("expected %d doubles, got %d" % (n, a.size))
+    return a
+
+
+def _dp(a):
+    return a.ctypes.data_as(c_double_p)
+
+
+class Context:
+    """nos_ctx: one HIP stream + workspace per listed device (include/nos.h)."""
+
+    def __init__(self, device_ids=(0,)):
+        self._lib = hip_lib()
+        ids = (ctypes.c_int * len(device_ids))(*device_ids)
+        h = ctypes.c_void_p()
+        check(self._lib.nos_ctx_create(ids, len(device_ids), ctypes.byref(h)), "nos_ctx_create")
+        self._h = h
+        self.device_ids = tuple(device_ids)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def set_stream(self, stream_ptr, shard=0):
+        check(self._lib.nos_ctx_set_stream(self._h, shard, ctypes.c_void_p(stream_ptr)), "nos_ctx_set_stream")
+
+    def use_torch_stream(self, shard=0):
+        import torch
+        self.set_stream(torch.cuda.current_stream().cuda_stream, shard)
+
+    def set_launch(self, blocks_per_cu=0, variant=0):
+        check(self._lib.nos_ctx_set_launch(self._h, blocks_per_cu, variant), "nos_ctx_set_launch")
+
+    def synchronize(self):
+        check(self._lib.nos_ctx_synchronize(self._h), "nos_ctx_synchronize")
+
+    def close(self):
+        if self._h:
+            self._lib.nos_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _Dataset:
+    _n_planes = 0
+    _create = _create_dev = _create_rec = None
+
+    def __init__(self, ctx, handle):
+        self._ctx = ctx
+        self._lib = ctx._lib
+        self._h = handle
+
+    @classmethod
+    def from_planes(cls, ctx, planes, dtype="f64"):
+        """planes: [n_planes, n] float64 host array (plane order of include/nos.h)."""
+        planes = np.ascontiguousarray(planes, dtype=np.float64)
+        if planes.ndim != 2 or planes.shape[0] != cls._n_planes:
+            raise ValueError("planes must be [%d, n]" % cls._n_planes)
+        arr = (c_double_p * cls._n_planes)(*[planes[k].ctypes.data_as(c_double_p) for k in range(cls._n_planes)])
+        h = ctypes.c_void_p()
+        fn = getattr(ctx._lib, cls._create)
+        check(fn(ctx.handle, planes.shape[1], arr, _DTYPES[dtype], ctypes.byref(h)), cls._create)
+        return cls(ctx, h)
+
+    @classmethod
+    def from_device_planes(cls, ctx, planes, dtype="f64"):
+        """planes: torch CUDA tensor [n_planes, n], float64 or float32, contiguous."""
+        import torch
+        if not planes.is_cuda or planes.dim() != 2 or planes.shape[0] != cls._n_planes or not planes.is_contiguous():
+            raise ValueError("planes must be a contiguous CUDA tensor [%d, n]" % cls._n_planes)
+        src = NOS_F64 if planes.dtype == torch.float64 else NOS_F32
+        if planes.dtype not in (torch.float64, torch.float32):
+            raise ValueError("planes must be float64 or float32")
+        n = planes.shape[1]
+        step = planes.element_size() * n
+        arr = (ctypes.c_void_p * cls._n_planes)(*[planes.data_ptr() + k * step for k in range(cls._n_planes)])
+        h = ctypes.c_void_p()
+        torch.cuda.current_stream().synchronize()
+        fn = getattr(ctx._lib, cls._create_dev)
+        check(fn(ctx.handle, n, arr, src, _DTYPES[dtype], ctypes.byref(h)), cls._create_dev)
+        return cls(ctx, h)
+
+    @classmethod
+    def from_records(cls, ctx, records, stride_bytes, field_offsets, dtype="f64"):
+        """records: host bytes-like / uint8 array of n*stride_bytes; field_offsets: byte offsets
+        of the n_planes doubles inside a record (AoS ingestion, include/nos.h)."""
+        rec = np.ascontiguousarray(np.frombuffer(records, dtype=np.uint8) if not isinstance(records, np.ndarray)
+                                   else records.view(np.uint8).reshape(-1))
+        if rec.size % stride_bytes != 0:
+            raise ValueError("records size is not a multiple of stride_bytes")
+        n = rec.size // stride_bytes
+        offs = (ctypes.c_size_t * cls._n_planes)(*[int(o) for o in field_offsets])
+        h = ctypes.c_void_p()
+        fn = getattr(ctx._lib, cls._create_rec)
+        check(fn(ctx.handle, n, rec.ctypes.data_as(ctypes.c_void_p), stride_bytes, offs, _DTYPES[dtype],
+                 ctypes.byref(h)), cls._create_rec)
+        return cls(ctx, h)
+
+    def __len__(self):
+        return int(self._lib.nos_dataset_size(self._h))
+
+    @property
+    def stream_bytes(self):
+        return int(self._lib.nos_dataset_stream_bytes(self._h))
+
+    @property
+    def dtype(self):
+        return "f32" if self._lib.nos_dataset_dtype(self._h) == NOS_F32 else "f64"
+
+    def close(self):
+        if self._h:
+            self._lib.nos_dataset_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class NdtDataset(_Dataset):
+    """Device-resident NDT correspondences (point, mean, sqrt-information)."""
+    _n_planes = 15
+    _create = "nos_ndt_dataset_create"
+    _create_dev = "nos_ndt_dataset_create_from_device"
+    _create_rec = "nos_ndt_dataset_create_from_records"
+
+    def accumulate6(self, R, t, loss=None):
+        R = _dvec(R, 9)
+        t = _dvec(t, 3)
+        out = np.zeros(28)
+        l = make_loss(loss)
+        check(self._lib.nos_ndt6_accumulate(self._h, _dp(R), _dp(t), ctypes.byref(l), _dp(out)), "nos_ndt6_accumulate")
+        return out
+
+    def accumulate6_async(self, R, t, loss, out_tensor):
+        """Enqueue on the context stream; result lands in the CUDA float64 tensor out_tensor[28]."""
+        R = _dvec(R, 9)
+        t = _dvec(t, 3)
+        l = make_loss(loss)
+        check(self._lib.nos_ndt6_accumulate_async(self._h, _dp(R), _dp(t), ctypes.byref(l),
+                                                  ctypes.c_void_p(out_tensor.data_ptr())), "nos_ndt6_accumulate_async")
+
+    def accumulate3(self, R2, t2, loss=None):
+        R2 = _dvec(R2, 4)
+        t2 = _dvec(t2, 2)
+        out = np.zeros(10)
+        l = make_loss(loss)
+        check(self._lib.nos_ndt3_accumulate(self._h, _dp(R2), _dp(t2), ctypes.byref(l), _dp(out)), "nos_ndt3_accumulate")
+        return out
+
+    def accumulate3_async(self, R2, t2, loss, out_tensor):
+        R2 = _dvec(R2, 4)
+        t2 = _dvec(t2, 2)
+        l = make_loss(loss)
+        check(self._lib.nos_ndt3_accumulate_async(self._h, _dp(R2), _dp(t2), ctypes.byref(l),
+                                                  ctypes.c_void_p(out_tensor.data_ptr())), "nos_ndt3_accumulate_async")
+
+    def time_kernel6(self, R, t, loss=None, repeats=20):
+        R = _dvec(R, 9)
+        t = _dvec(t, 3)
+        l = make_loss(loss)
+        k = ctypes.c_double()
+        tot = ctypes.c_double()
+        check(self._lib.nos_ndt6_time_kernel(self._h, _dp(R), _dp(t), ctypes.byref(l), repeats, ctypes.byref(k),
+                                             ctypes.byref(tot)), "nos_ndt6_time_kernel")
+        return k.value, tot.value
+
+    def time_kernel3(self, R2, t2, loss=None, repeats=20):
+        R2 = _dvec(R2, 4)
+        t2 = _dvec(t2, 2)
+        l = make_loss(loss)
+        k = ctypes.c_double()
+        tot = ctypes.c_double()
+        check(self._lib.nos_ndt3_time_kernel(self._h, _dp(R2), _dp(t2), ctypes.byref(l), repeats, ctypes.byref(k),
+                                             ctypes.byref(tot)), "nos_ndt3_time_kernel")
+        return k.value, tot.value
+
+
+class ReprojDataset(_Dataset):
+    """Device-resident 3D↔2D correspondences (X, Y, Z, u, v)."""
+    _n_planes = 5
+    _create = "nos_reproj_dataset_create"
+    _create_dev = "nos_reproj_dataset_create_from_device"
+    _create_rec = "nos_reproj_dataset_create_from_records"
+
+    def accumulate(self, R, t, intr, loss=None, min_depth=0.03):
+        R = _dvec(R, 9)
+        t = _dvec(t, 3)
+        intr = _dvec(intr, 4)
+        out = np.zeros(28)
+        l = make_loss(loss)
+        check(self._lib.nos_reproj_accumulate(self._h, _dp(R), _dp(t), _dp(intr), ctypes.byref(l),
+                                              ctypes.c_double(min_depth), _dp(out)), "nos_reproj_accumulate")
+        return out
+
+    def accumulate_async(self, R, t, intr, loss, out_tensor, min_depth=0.03):
+        R = _dvec(R, 9)
+        t = _dvec(t, 3)
+        intr = _dvec(intr, 4)
+        l = make_loss(loss)
+        check(self._lib.nos_reproj_accumulate_async(self._h, _dp(R), _dp(t), _dp(intr), ctypes.byref(l),
+                                                    ctypes.c_double(min_depth),
+                                                    ctypes.c_void_p(out_tensor.data_ptr())),
+              "nos_reproj_accumulate_async")
+
+    def time_kernel(self, R, t, intr, loss=None, min_depth=0.03, repeats=20):
+        R = _dvec(R, 9)
+        t = _dvec(t, 3)
+        intr = _dvec(intr, 4)
+        l = make_loss(loss)
+        k = ctypes.c_double()
+        tot = ctypes.c_double()
+        check(self._lib.nos_reproj_time_kernel(self._h, _dp(R), _dp(t), _dp(intr), ctypes.byref(l),
+                                               ctypes.c_double(min_depth), repeats, ctypes.byref(k),
+                                               ctypes.byref(tot)), "nos_reproj_time_kernel")
+        return k.value, tot.value

@@ -1,0 +1,445 @@
+// assemble_kernels.hpp — hand-written gfx950 (CDNA4, wave64) kernels for the Gauss-Newton
+// normal-equation assembly path.
+//
+// One streaming pass per LM iteration: every lane reads ITEMS consecutive correspondences
+// from a tiled struct-of-arrays dataset (one wide load per field), evaluates residual,
+// analytic Jacobian and robust weight in registers, and keeps the 28 (or 10) running sums
+// of  H = Σ w JᵀJ (upper triangle),  g = Σ w Jᵀr,  cost = Σ ρ  in registers for the whole
+// grid-stride loop.  The sums leave the lane exactly once: wave64 butterfly → LDS across
+// the block's waves → one row of `partials`, then a fixed-order final pass → 28 doubles.
+// No atomics, so results are bit-reproducible for a fixed launch geometry.
+//
+// Bound: HBM bandwidth (120 B fp64 / 60 B fp32 per correspondence, ≈200 VALU ops); the
+// contraction is a fixed 6×6 outer product so MFMA is deliberately not used.
+//
+// Math restated from (reference paths relative to nonlinear_optimizer/):
+//   6-DoF NDT     mahalanobis_distance_minimizer/mahalanobis_distance_minimizer_analytic.cc:159-185
+//                 (lane form: ..._analytic_simd_various.cc:656-697)
+//   3-DoF NDT     mahalanobis_distance_minimizer/mahalanobis_distance_minimizer_analytic_3dof.cc:110-139
+//   reprojection  reprojection_error_minimizer/reprojection_error_minimizer_analytic.cc:107-162
+//   robust loss   loss_function.h:28-33, 57-66
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nos {
+
+constexpr int kWave = 64;
+
+enum LossKind : int { kLossNone = 0, kLossExponential = 1, kLossHuber = 2 };
+
+// Tiled SoA addressing.  Correspondence i, field f lives at element offset
+//   (i >> tile_shift) * tile_stride + f * field_stride + (i & (tile - 1)).
+// tile == n_padded, tile_stride == 0 gives a plain planar layout.
+struct TiledLayout {
+  const void* base;
+  uint64_t n;            // real correspondences
+  uint64_t n_padded;     // multiple of tile (pads are all-zero records)
+  uint64_t tile_stride;  // elements between consecutive tiles
+  uint64_t field_stride; // elements between consecutive fields inside a tile
+  uint32_t tile_shift;   // log2(tile)
+  uint32_t tile_mask;    // tile - 1
+};
+
+template <typename T>
+struct Ndt6Params {
+  T R[9];
+  T t[3];
+  T la, lb, lc;  // loss: (c1, c2, 2*c1*c2) | (th, th*th, 2*th)
+};
+
+template <typename T>
+struct Ndt3Params {
+  T R2[4];
+  T t2[2];
+  T la, lb, lc;
+};
+
+template <typename T>
+struct ReprojParams {
+  T R[9];
+  T t[3];
+  T inv_fx, inv_fy, cx, cy;
+  T min_depth;
+  T la, lb, lc;
+};
+
+// ---------------------------------------------------------------- math helpers
+
+template <typename T>
+__device__ __forceinline__ T fast_exp(T x);
+template <>
+__device__ __forceinline__ double fast_exp<double>(double x) {
+  return exp(x);
+}
+template <>
+__device__ __forceinline__ float fast_exp<float>(float x) {
+  return __expf(x);
+}
+template <typename T>
+__device__ __forceinline__ T fast_sqrt(T x);
+template <>
+__device__ __forceinline__ double fast_sqrt<double>(double x) {
+  return sqrt(x);
+}
+template <>
+__device__ __forceinline__ float fast_sqrt<float>(float x) {
+  return sqrtf(x);
+}
+
+// loss_function.h:28-33 / :57-66 ; LOSS == 0 is the `loss_function_ == nullptr` branch.
+template <typename T, int LOSS>
+__device__ __forceinline__ void loss_eval(T s, T la, T lb, T lc, T& rho, T& w) {
+  if constexpr (LOSS == kLossExponential) {
+    const T ex = fast_exp<T>(-lb * s);
+    rho = la - la * ex;
+    w = lc * ex;
+  } else if constexpr (LOSS == kLossHuber) {
+    const bool outlier = s > lb;           // lb = th^2
+    const T rr = fast_sqrt<T>(outlier ? s : T(1));
+    rho = outlier ? (lc * rr - lb) : s;    // lc = 2 th
+    w = outlier ? (la / rr) : T(1);
+  } else {
+    rho = s;
+    w = T(1);
+  }
+}
+
+// acc += w * JᵀJ (upper), w * Jᵀr for a ROWS×6 Jacobian held as J[row][6].
+template <typename T, int ROWS>
+__device__ __forceinline__ void rank_update6(const T (&J)[ROWS][6], const T (&r)[ROWS], T w,
+                                             T rho, T (&acc)[28]) {
+  T wJ[ROWS][6];
+#pragma unroll
+  for (int a = 0; a < ROWS; ++a)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) wJ[a][c] = w * J[a][c];
+  int k = 0;
+#pragma unroll
+  for (int row = 0; row < 6; ++row)
+#pragma unroll
+    for (int col = row; col < 6; ++col) {
+      T h = acc[k];
+#pragma unroll
+      for (int a = 0; a < ROWS; ++a) h = fma(wJ[a][row], J[a][col], h);
+      acc[k] = h;
+      ++k;
+    }
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    T gsum = acc[21 + c];
+#pragma unroll
+    for (int a = 0; a < ROWS; ++a) gsum = fma(wJ[a][c], r[a], gsum);
+    acc[21 + c] = gsum;
+  }
+  acc[27] += rho;
+}
+
+// M = -R [p]x, column form of ..._analytic_simd_various.cc:677-687.
+template <typename T>
+__device__ __forceinline__ void minus_R_hat(const T (&R)[9], T px, T py, T pz, T (&M)[3][3]) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    M[i][0] = fma(R[3 * i + 2], py, -(R[3 * i + 1] * pz));
+    M[i][1] = fma(R[3 * i + 0], pz, -(R[3 * i + 2] * px));
+    M[i][2] = fma(R[3 * i + 1], px, -(R[3 * i + 0] * py));
+  }
+}
+
+// ---------------------------------------------------------------- problems
+
+template <typename T, int LOSS>
+struct Ndt6Problem {
+  static constexpr int kFields = 15;
+  static constexpr int kOut = 28;
+  using Params = Ndt6Params<T>;
+  // x = {p(3), mu(3), S row-major (9)}
+  __device__ static __forceinline__ void item(const T (&x)[15], const Params& P, bool /*valid*/,
+                                              T (&acc)[28]) {
+    T e[3], r[3], M[3][3], J[3][6];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const T pw = fma(P.R[3 * i], x[0], fma(P.R[3 * i + 1], x[1], fma(P.R[3 * i + 2], x[2], P.t[i])));
+      e[i] = pw - x[3 + i];
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+      r[a] = fma(x[6 + 3 * a], e[0], fma(x[7 + 3 * a], e[1], x[8 + 3 * a] * e[2]));
+    minus_R_hat<T>(P.R, x[0], x[1], x[2], M);
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        J[a][b] = x[6 + 3 * a + b];
+        J[a][3 + b] = fma(x[6 + 3 * a], M[0][b], fma(x[7 + 3 * a], M[1][b], x[8 + 3 * a] * M[2][b]));
+      }
+    const T s = fma(r[0], r[0], fma(r[1], r[1], r[2] * r[2]));
+    T rho, w;
+    loss_eval<T, LOSS>(s, P.la, P.lb, P.lc, rho, w);
+    // zero-padded records have S = 0 → r = 0, J = 0, rho(0) = 0: no mask needed
+    rank_update6<T, 3>(J, r, w, rho, acc);
+  }
+};
+
+template <typename T, int LOSS>
+struct Ndt3Problem {
+  static constexpr int kFields = 15;
+  static constexpr int kOut = 10;
+  using Params = Ndt3Params<T>;
+  __device__ static __forceinline__ void item(const T (&x)[15], const Params& P, bool /*valid*/,
+                                              T (&acc)[10]) {
+    T e[3], r[3], J[3][3];
+    const T ux = x[0], uy = x[1];
+    e[0] = fma(P.R2[0], ux, fma(P.R2[1], uy, P.t2[0])) - x[3];
+    e[1] = fma(P.R2[2], ux, fma(P.R2[3], uy, P.t2[1])) - x[4];
+    e[2] = x[2] - x[5];
+    const T d0 = fma(P.R2[1], ux, -(P.R2[0] * uy));
+    const T d1 = fma(P.R2[3], ux, -(P.R2[2] * uy));
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      r[a] = fma(x[6 + 3 * a], e[0], fma(x[7 + 3 * a], e[1], x[8 + 3 * a] * e[2]));
+      J[a][0] = x[6 + 3 * a];
+      J[a][1] = x[7 + 3 * a];
+      J[a][2] = fma(x[6 + 3 * a], d0, x[7 + 3 * a] * d1);
+    }
+    const T s = fma(r[0], r[0], fma(r[1], r[1], r[2] * r[2]));
+    T rho, w;
+    loss_eval<T, LOSS>(s, P.la, P.lb, P.lc, rho, w);
+    T wJ[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) wJ[a][c] = w * J[a][c];
+    int k = 0;
+#pragma unroll
+    for (int row = 0; row < 3; ++row)
+#pragma unroll
+      for (int col = row; col < 3; ++col) {
+        acc[k] = fma(wJ[0][row], J[0][col], fma(wJ[1][row], J[1][col], fma(wJ[2][row], J[2][col], acc[k])));
+        ++k;
+      }
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      acc[6 + c] = fma(wJ[0][c], r[0], fma(wJ[1][c], r[1], fma(wJ[2][c], r[2], acc[6 + c])));
+    acc[9] += rho;
+  }
+};
+
+template <typename T, int LOSS>
+struct ReprojProblem {
+  static constexpr int kFields = 5;
+  static constexpr int kOut = 28;
+  using Params = ReprojParams<T>;
+  // x = {X(3), pixel(2)}
+  __device__ static __forceinline__ void item(const T (&x)[5], const Params& P, bool valid,
+                                              T (&acc)[28]) {
+    T Xw[3], M[3][3], J[2][6], r[2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      Xw[i] = fma(P.R[3 * i], x[0], fma(P.R[3 * i + 1], x[1], fma(P.R[3 * i + 2], x[2], P.t[i])));
+    // depth test of ..._analytic.cc:119-123; pads (valid == false) contribute nothing
+    const bool ok = valid && !(Xw[2] < P.min_depth);
+    const T iz = T(1) / (ok ? Xw[2] : T(1));
+    const T iz2 = iz * iz;
+    r[0] = fma(Xw[0], iz, -(P.inv_fx * (x[3] - P.cx)));
+    r[1] = fma(Xw[1], iz, -(P.inv_fy * (x[4] - P.cy)));
+    minus_R_hat<T>(P.R, x[0], x[1], x[2], M);
+    const T k02 = -Xw[0] * iz2, k12 = -Xw[1] * iz2;
+    J[0][0] = iz;
+    J[0][1] = T(0);
+    J[0][2] = k02;
+    J[1][0] = T(0);
+    J[1][1] = iz;
+    J[1][2] = k12;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      J[0][3 + b] = fma(iz, M[0][b], k02 * M[2][b]);
+      J[1][3 + b] = fma(iz, M[1][b], k12 * M[2][b]);
+    }
+    const T s = fma(r[0], r[0], r[1] * r[1]);
+    T rho, w;
+    loss_eval<T, LOSS>(ok ? s : T(0), P.la, P.lb, P.lc, rho, w);
+    w = ok ? w : T(0);
+    rho = ok ? rho : T(0);
+    rank_update6<T, 2>(J, r, w, rho, acc);
+  }
+};
+
+// ---------------------------------------------------------------- loads
+
+template <typename T, int N>
+struct VecOf;
+template <>
+struct VecOf<double, 1> { using type = double; };
+template <>
+struct VecOf<double, 2> { using type = double __attribute__((ext_vector_type(2))); };
+template <>
+struct VecOf<float, 1> { using type = float; };
+template <>
+struct VecOf<float, 2> { using type = float __attribute__((ext_vector_type(2))); };
+template <>
+struct VecOf<float, 4> { using type = float __attribute__((ext_vector_type(4))); };
+
+template <typename T, int N, bool NT>
+__device__ __forceinline__ void load_items(const T* p, T (&dst)[N]) {
+  using V = typename VecOf<T, N>::type;
+  const V* vp = reinterpret_cast<const V*>(p);
+  V v;
+  if constexpr (NT)
+    v = __builtin_nontemporal_load(vp);
+  else
+    v = *vp;
+  if constexpr (N == 1) {
+    dst[0] = v;
+  } else {
+#pragma unroll
+    for (int k = 0; k < N; ++k) dst[k] = v[k];
+  }
+}
+
+// ---------------------------------------------------------------- reduction
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+  return v;
+}
+
+// Sums acc[] over the block and writes one row of kOut doubles.  Fixed order:
+// butterfly inside a wave, then waves 0..W-1.
+template <int NOUT, int BLOCK>
+__device__ __forceinline__ void block_reduce_store(const double (&acc)[NOUT], double* row) {
+  constexpr int kWaves = BLOCK / kWave;
+  __shared__ double lds[kWaves][NOUT];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x / kWave;
+#pragma unroll
+  for (int k = 0; k < NOUT; ++k) {
+    const double s = wave_sum(acc[k]);
+    if (lane == 0) lds[wave][k] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < NOUT) {
+    double s = 0.0;
+#pragma unroll
+    for (int wv = 0; wv < kWaves; ++wv) s += lds[wv][threadIdx.x];
+    row[threadIdx.x] = s;
+  }
+}
+
+// ---------------------------------------------------------------- the assemble kernel
+
+// Grid-stride over chunks of BLOCK*ITEMS correspondences.  `n_chunks * BLOCK * ITEMS`
+// must equal L.n_padded and the tile size must be a multiple of BLOCK*ITEMS (checked on
+// the host before launch).
+template <typename Problem, typename T, int ITEMS, int BLOCK, int MINW, bool NT>
+__global__ __launch_bounds__(BLOCK, MINW) void assemble_kernel(TiledLayout L,
+                                                              typename Problem::Params P,
+                                                              uint32_t n_chunks,
+                                                              double* __restrict__ partials) {
+  constexpr int kF = Problem::kFields;
+  constexpr int kOut = Problem::kOut;
+  constexpr uint32_t kChunk = BLOCK * ITEMS;
+  const T* __restrict__ base = static_cast<const T*>(L.base);
+
+  T acc[kOut];
+#pragma unroll
+  for (int k = 0; k < kOut; ++k) acc[k] = T(0);
+
+  for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    const uint64_t i0 = uint64_t(c) * kChunk + uint64_t(threadIdx.x) * ITEMS;
+    const uint64_t off = (i0 >> L.tile_shift) * L.tile_stride + (i0 & L.tile_mask);
+    T x[kF][ITEMS];
+#pragma unroll
+    for (int f = 0; f < kF; ++f) load_items<T, ITEMS, NT>(base + off + uint64_t(f) * L.field_stride, x[f]);
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      T xi[kF];
+#pragma unroll
+      for (int f = 0; f < kF; ++f) xi[f] = x[f][it];
+      Problem::item(xi, P, (i0 + it) < L.n, acc);
+    }
+  }
+
+  double dacc[kOut];
+#pragma unroll
+  for (int k = 0; k < kOut; ++k) dacc[k] = double(acc[k]);
+  block_reduce_store<kOut, BLOCK>(dacc, partials + size_t(blockIdx.x) * kOut);
+}
+
+// Fixed-order sum of the block rows: thread (slice, col) adds rows slice, slice+S, …;
+// then the S slice sums are added in slice order.  One block, 1024 threads.
+template <int NOUT>
+__global__ __launch_bounds__(1024) void final_reduce_kernel(const double* __restrict__ partials,
+                                                            uint32_t n_rows,
+                                                            double* __restrict__ out) {
+  constexpr int kCols = 32;
+  constexpr int kSlices = 1024 / kCols;
+  __shared__ double lds[kSlices][kCols];
+  const int col = threadIdx.x % kCols;
+  const int slice = threadIdx.x / kCols;
+  double s = 0.0;
+  if (col < NOUT)
+    for (uint32_t r = slice; r < n_rows; r += kSlices) s += partials[size_t(r) * NOUT + col];
+  lds[slice][col] = s;
+  __syncthreads();
+  if (threadIdx.x < NOUT) {
+    double tot = 0.0;
+#pragma unroll
+    for (int sl = 0; sl < kSlices; ++sl) tot += lds[sl][threadIdx.x];
+    out[threadIdx.x] = tot;
+  }
+}
+
+// ---------------------------------------------------------------- ingestion kernels
+
+// planar source planes (15 or 5 pointers, element type SRC) → tiled layout of DST, zero pads.
+struct PlanePtrs {
+  const void* p[15];
+};
+
+template <typename SRC, typename DST>
+__global__ __launch_bounds__(256) void retile_kernel(PlanePtrs src, int n_fields, TiledLayout L,
+                                                     DST* __restrict__ dst) {
+  const uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x;
+  const int f = blockIdx.y;
+  if (i >= L.n_padded || f >= n_fields) return;
+  const uint64_t off = (i >> L.tile_shift) * L.tile_stride + uint64_t(f) * L.field_stride + (i & L.tile_mask);
+  DST v = DST(0);
+  if (i < L.n) v = DST(static_cast<const SRC*>(src.p[f])[i]);
+  dst[off] = v;
+}
+
+// array-of-structures records (double fields at byte offsets) → tiled layout.
+// `first` is the index of records[0] inside the dataset; count records are unpacked.
+struct FieldOffsets {
+  uint32_t off[15];
+};
+
+template <typename DST>
+__global__ __launch_bounds__(256) void unpack_records_kernel(const unsigned char* __restrict__ records,
+                                                             uint64_t stride_bytes, FieldOffsets fo,
+                                                             int n_fields, uint64_t first,
+                                                             uint64_t count, TiledLayout L,
+                                                             DST* __restrict__ dst) {
+  const uint64_t j = uint64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (j >= count) return;
+  const unsigned char* rec = records + j * stride_bytes;
+  const uint64_t i = first + j;
+  const uint64_t o = (i >> L.tile_shift) * L.tile_stride + (i & L.tile_mask);
+  for (int f = 0; f < n_fields; ++f) {
+    const double v = *reinterpret_cast<const double*>(rec + fo.off[f]);
+    dst[o + uint64_t(f) * L.field_stride] = DST(v);
+  }
+}
+
+template <typename DST>
+__global__ __launch_bounds__(256) void zero_pad_kernel(int n_fields, TiledLayout L, DST* __restrict__ dst) {
+  const uint64_t i = L.n + uint64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= L.n_padded) return;
+  const uint64_t o = (i >> L.tile_shift) * L.tile_stride + (i & L.tile_mask);
+  for (int f = 0; f < n_fields; ++f) dst[o + uint64_t(f) * L.field_stride] = DST(0);
+}
+
+}  // namespace nos

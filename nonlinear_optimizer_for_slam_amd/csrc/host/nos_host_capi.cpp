@@ -1,0 +1,233 @@
+// nos_host_capi.cpp — C entry points that drive the C++ drop-in solver classes
+// (nos_hip_solvers.hpp) exactly the way a C++ caller of the reference would: build a
+// std::vector<Correspondence> (array of structures), set a LossFunction object, call Solve().
+// They exist so the Python test-suite and bench can exercise the C++ host layer; they add no
+// arithmetic of their own.
+#include <cstddef>
+#include <memory>
+#include <vector>
+
+#include "nos_hip_solvers.hpp"
+
+using nonlinear_optimizer::ExponentialLossFunction;
+using nonlinear_optimizer::HipOptions;
+using nonlinear_optimizer::HipSolveReport;
+using nonlinear_optimizer::HuberLossFunction;
+using nonlinear_optimizer::LossFunction;
+using nonlinear_optimizer::Options;
+using nonlinear_optimizer::Pose;
+
+namespace {
+
+std::shared_ptr<LossFunction> MakeLoss(int kind, double a, double b) {
+  if (kind == NOS_LOSS_EXPONENTIAL) return std::make_shared<ExponentialLossFunction>(a, b);
+  if (kind == NOS_LOSS_HUBER) return std::make_shared<HuberLossFunction>(a);
+  return nullptr;
+}
+
+HipOptions MakeHipOptions(int dtype, const int* device_ids, int n_devices, int print_cost_line) {
+  HipOptions h;
+  h.dtype = dtype;
+  h.print_cost_line = print_cost_line != 0;
+  if (device_ids != nullptr && n_devices > 0) h.device_ids.assign(device_ids, device_ids + n_devices);
+  return h;
+}
+
+Options MakeOptions(int max_iterations, double gradient_tolerance, double parameter_tolerance) {
+  Options o;
+  o.max_iterations = max_iterations;
+  o.convergence_handle.gradient_tolerance = gradient_tolerance;
+  o.convergence_handle.parameter_tolerance = parameter_tolerance;
+  return o;
+}
+
+void LoadPose(const double t[3], const double R[9], Pose* pose) {
+  for (int i = 0; i < 3; ++i) {
+    pose->translation()(i) = t[i];
+    for (int j = 0; j < 3; ++j) pose->linear()(i, j) = R[3 * i + j];
+  }
+}
+
+void StorePose(const Pose& pose, double t[3], double R[9]) {
+  for (int i = 0; i < 3; ++i) {
+    t[i] = pose.translation()(i);
+    for (int j = 0; j < 3; ++j) R[3 * i + j] = pose.linear()(i, j);
+  }
+}
+
+void StoreReport(const HipSolveReport& r, double report[5]) {
+  if (report == nullptr) return;
+  report[0] = r.iterations;
+  report[1] = r.printed_cost;
+  report[2] = r.last_cost;
+  report[3] = r.final_lambda;
+  report[4] = r.status;
+}
+
+}  // namespace
+
+extern "C" {
+
+// dof: 6 → MahalanobisDistanceMinimizerHip, 3 → MahalanobisDistanceMinimizerHip3DOF.
+// repeat_solves > 1 re-solves from the same initial pose on the prepared dataset (the additive
+// Prepare/SolvePrepared API) and returns the last result.  Returns 1 on success, 0 on failure
+// (the bool of Solve()).
+int nos_host_ndt_solve(int dof, size_t n, const double* const planes[15], int loss_kind, double loss_a,
+                       double loss_b, int max_iterations, double gradient_tolerance, double parameter_tolerance,
+                       int dtype, const int* device_ids, int n_devices, int print_cost_line, int repeat_solves,
+                       double t[3], double R[9], double report[5]) {
+  namespace mdm = nonlinear_optimizer::mahalanobis_distance_minimizer;
+  try {
+    std::vector<mdm::Correspondence> correspondences(n);
+    for (size_t i = 0; i < n; ++i) {
+      mdm::Correspondence& c = correspondences[i];
+      for (int k = 0; k < 3; ++k) {
+        c.point(k) = planes[k][i];
+        c.ndt.mean(k) = planes[3 + k][i];
+        for (int j = 0; j < 3; ++j) c.ndt.sqrt_information(k, j) = planes[6 + 3 * k + j][i];
+      }
+      c.ndt.is_valid = true;
+    }
+    const HipOptions hip = MakeHipOptions(dtype, device_ids, n_devices, print_cost_line);
+    std::unique_ptr<mdm::MahalanobisDistanceMinimizerHip> solver;
+    if (dof == 3)
+      solver = std::make_unique<mdm::MahalanobisDistanceMinimizerHip3DOF>(hip);
+    else
+      solver = std::make_unique<mdm::MahalanobisDistanceMinimizerHip>(hip);
+    solver->SetLossFunction(MakeLoss(loss_kind, loss_a, loss_b));
+    const Options options = MakeOptions(max_iterations, gradient_tolerance, parameter_tolerance);
+    Pose pose = Pose::Identity();
+    bool ok = false;
+    if (repeat_solves <= 1) {
+      LoadPose(t, R, &pose);
+      ok = solver->Solve(options, correspondences, &pose);
+    } else {
+      ok = solver->Prepare(correspondences);
+      for (int r = 0; ok && r < repeat_solves; ++r) {
+        LoadPose(t, R, &pose);
+        ok = solver->SolvePrepared(options, &pose);
+      }
+      solver->ReleasePrepared();
+    }
+    StoreReport(solver->report(), report);
+    if (ok) StorePose(pose, t, R);
+    return ok ? 1 : 0;
+  } catch (...) {
+    return 0;
+  }
+}
+
+// intr = {fx, fy, cx, cy}; inv_fx / inv_fy are derived as the reference's test does
+// (REM/tests/simple_optimization_test.cc:43-51).
+int nos_host_reproj_solve(size_t n, const double* const planes[5], const double intr[4], int loss_kind, double loss_a,
+                          double loss_b, int max_iterations, double gradient_tolerance, double parameter_tolerance,
+                          int dtype, const int* device_ids, int n_devices, int print_cost_line, double t[3],
+                          double R[9], double report[5]) {
+  namespace rem = nonlinear_optimizer::reprojection_error_minimizer;
+  try {
+    std::vector<rem::Correspondence> correspondences(n);
+    for (size_t i = 0; i < n; ++i) {
+      for (int k = 0; k < 3; ++k) correspondences[i].local_point(k) = planes[k][i];
+      correspondences[i].matched_pixel(0) = planes[3][i];
+      correspondences[i].matched_pixel(1) = planes[4][i];
+    }
+    rem::CameraIntrinsics cam;
+    cam.fx = intr[0];
+    cam.fy = intr[1];
+    cam.cx = intr[2];
+    cam.cy = intr[3];
+    cam.inv_fx = 1.0 / cam.fx;
+    cam.inv_fy = 1.0 / cam.fy;
+    cam.width = 640;
+    cam.height = 480;
+    rem::ReprojectionErrorMinimizerHip solver(MakeHipOptions(dtype, device_ids, n_devices, print_cost_line));
+    solver.SetLossFunction(MakeLoss(loss_kind, loss_a, loss_b));
+    const Options options = MakeOptions(max_iterations, gradient_tolerance, parameter_tolerance);
+    Pose pose = Pose::Identity();
+    LoadPose(t, R, &pose);
+    const bool ok = solver.Solve(options, correspondences, cam, &pose);
+    StoreReport(solver.report(), report);
+    if (ok) StorePose(pose, t, R);
+    return ok ? 1 : 0;
+  } catch (...) {
+    return 0;
+  }
+}
+
+// Loss-descriptor recovery exposed for CPU-only unit tests (no GPU involved).
+int nos_host_describe_loss(int kind, double a, double b, int* out_kind, double* out_a, double* out_b) {
+  try {
+    std::shared_ptr<LossFunction> loss = MakeLoss(kind, a, b);
+    nos_loss d;
+    const bool ok = nonlinear_optimizer::DescribeLossFunction(loss.get(), &d);
+    *out_kind = d.kind;
+    *out_a = d.a;
+    *out_b = d.b;
+    return ok ? 1 : 0;
+  } catch (...) {
+    return 0;
+  }
+}
+
+size_t nos_host_sizeof_ndt_correspondence(void) {
+  return sizeof(nonlinear_optimizer::mahalanobis_distance_minimizer::Correspondence);
+}
+
+}  // extern "C"
+
+// ---- host-logic hooks (no GPU): the LM loop and the damped step with a caller-supplied
+// accumulate callback, so the C++ host layer can be unit-tested on a CPU-only box and so a
+// one-process-per-GPU caller can put an all-reduce between the kernel and the host step. ----
+#include "nos_lm.hpp"
+
+extern "C" {
+
+typedef int (*nos_host_accumulate6_fn)(void* user, const double R[9], const double t[3], double out28[28]);
+typedef int (*nos_host_accumulate3_fn)(void* user, const double R2[4], const double t2[2], double out10[10]);
+
+// Returns 1 if the loop ran to a normal end, 0 if the callback or the 6x6 solve failed.
+int nos_host_lm6_run(nos_host_accumulate6_fn accumulate, void* user, int max_iterations, double gradient_tolerance,
+                     double parameter_tolerance, double t[3], double R[9], double report[5]) {
+  nos_host::LmSettings s;
+  s.max_iterations = max_iterations;
+  s.gradient_tolerance = gradient_tolerance;
+  s.parameter_tolerance = parameter_tolerance;
+  const nos_host::LmReport lm = nos_host::RunLm6(
+      s, [&](const double* Rc, const double* tc, double* out) { return accumulate(user, Rc, tc, out) == 0; }, t, R);
+  if (report != nullptr) {
+    report[0] = lm.iterations;
+    report[1] = lm.printed_cost;
+    report[2] = lm.last_cost;
+    report[3] = lm.final_lambda;
+    report[4] = lm.ok ? 0 : 1;
+  }
+  return lm.ok ? 1 : 0;
+}
+
+int nos_host_lm3_run(nos_host_accumulate3_fn accumulate, void* user, int max_iterations, double gradient_tolerance,
+                     double parameter_tolerance, double t2[2], double R2[4], double report[5]) {
+  nos_host::LmSettings s;
+  s.max_iterations = max_iterations;
+  s.gradient_tolerance = gradient_tolerance;
+  s.parameter_tolerance = parameter_tolerance;
+  const nos_host::LmReport lm = nos_host::RunLm3(
+      s, [&](const double* Rc, const double* tc, double* out) { return accumulate(user, Rc, tc, out) == 0; }, t2, R2);
+  if (report != nullptr) {
+    report[0] = lm.iterations;
+    report[1] = lm.printed_cost;
+    report[2] = lm.last_cost;
+    report[3] = lm.final_lambda;
+    report[4] = lm.ok ? 0 : 1;
+  }
+  return lm.ok ? 1 : 0;
+}
+
+int nos_host_damped_step6(const double out28[28], double lambda, double step[6]) {
+  return nos_host::DampedStep<6>(out28, lambda, step) ? 1 : 0;
+}
+
+int nos_host_damped_step3(const double out10[10], double lambda, double step[3]) {
+  return nos_host::DampedStep<3>(out10, lambda, step) ? 1 : 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,277 @@
+// nos_lm.hpp — host side of one Levenberg-Marquardt solve around the GPU assembly.
+//
+// The outer loop of the reference is kept as it is (north star: "loss_function.h, options.h
+// and the outer LM loop are unchanged"): multiplicative damping H_kk *= 1 + λ, a tiny dense
+// solve on the host, right-multiplicative pose update, convergence tested after the update,
+// λ schedule ×2 / ×0.6 clamped to the hard-coded [1e-6, 1e-2].  Restated from
+//   NO/mahalanobis_distance_minimizer/mahalanobis_distance_minimizer_analytic_simd.cc:30-108
+//   NO/mahalanobis_distance_minimizer/mahalanobis_distance_minimizer_analytic_3dof.cc:17-108
+//   NO/reprojection_error_minimizer/reprojection_error_minimizer_analytic.cc:15-105
+// Only plain doubles appear here so the same code serves an Eigen build of the reference
+// tree and the Eigen-free build of this repository.
+#ifndef NOS_LM_HPP_
+#define NOS_LM_HPP_
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+
+#if defined(NOS_USE_EIGEN) && __has_include(<Eigen/Dense>)
+#include <Eigen/Dense>
+#define NOS_HAVE_EIGEN 1
+#endif
+
+namespace nos_host {
+
+struct Quat {  // w, x, y, z
+  double w = 1.0, x = 0.0, y = 0.0, z = 0.0;
+};
+
+// Rotation matrix (row-major) → unit quaternion, the branch structure Eigen's
+// Quaternion(Matrix3) uses, so the starting orientation equals the reference's
+// `Orientation optimized_orientation(initial_pose.rotation())`.
+inline Quat QuatFromMatrix(const double R[9]) {
+  Quat q;
+  const double tr = R[0] + R[4] + R[8];
+  if (tr > 0.0) {
+    const double s = std::sqrt(tr + 1.0);
+    const double f = 0.5 / s;
+    q.w = 0.5 * s;
+    q.x = (R[7] - R[5]) * f;
+    q.y = (R[2] - R[6]) * f;
+    q.z = (R[3] - R[1]) * f;
+    return q;
+  }
+  int i = (R[4] > R[0]) ? 1 : 0;
+  if (R[8] > R[4 * i]) i = 2;
+  const int j = (i + 1) % 3, k = (j + 1) % 3;
+  const double s = std::sqrt(R[4 * i] - R[4 * j] - R[4 * k] + 1.0);
+  const double f = 0.5 / s;
+  double v[3];
+  v[i] = 0.5 * s;
+  v[j] = (R[3 * j + i] + R[3 * i + j]) * f;
+  v[k] = (R[3 * k + i] + R[3 * i + k]) * f;
+  q.w = (R[3 * k + j] - R[3 * j + k]) * f;
+  q.x = v[0];
+  q.y = v[1];
+  q.z = v[2];
+  return q;
+}
+
+inline void QuatToMatrix(const Quat& q, double R[9]) {
+  const double tx = 2.0 * q.x, ty = 2.0 * q.y, tz = 2.0 * q.z;
+  const double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
+  const double txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
+  const double tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+  R[0] = 1.0 - (tyy + tzz);
+  R[1] = txy - twz;
+  R[2] = txz + twy;
+  R[3] = txy + twz;
+  R[4] = 1.0 - (txx + tzz);
+  R[5] = tyz - twx;
+  R[6] = txz - twy;
+  R[7] = tyz + twx;
+  R[8] = 1.0 - (txx + tyy);
+}
+
+// so(3) → quaternion, MahalanobisDistanceMinimizer::ComputeQuaternion
+// (NO/mahalanobis_distance_minimizer/mahalanobis_distance_minimizer.cc:20-33).
+inline Quat ExpQuat(const double w[3]) {
+  Quat q;
+  const double theta = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+  if (theta < 1e-6) {
+    q.w = 1.0;
+    q.x = 0.5 * w[0];
+    q.y = 0.5 * w[1];
+    q.z = 0.5 * w[2];
+  } else {
+    const double half = 0.5 * theta;
+    const double k = std::sin(half) / theta;
+    q.w = std::cos(half);
+    q.x = k * w[0];
+    q.y = k * w[1];
+    q.z = k * w[2];
+  }
+  return q;
+}
+
+// q ← normalize(q ⊗ dq)
+inline void RightMultiplyNormalize(Quat* q, const Quat& d) {
+  const Quat a = *q;
+  Quat r;
+  r.w = a.w * d.w - a.x * d.x - a.y * d.y - a.z * d.z;
+  r.x = a.w * d.x + a.x * d.w + a.y * d.z - a.z * d.y;
+  r.y = a.w * d.y + a.y * d.w + a.z * d.x - a.x * d.z;
+  r.z = a.w * d.z + a.z * d.w + a.x * d.y - a.y * d.x;
+  const double n = std::sqrt(r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w);
+  q->w = r.w / n;
+  q->x = r.x / n;
+  q->y = r.y / n;
+  q->z = r.z / n;
+}
+
+// Solve (A) x = b for a symmetric positive definite A (N ≤ 6) by LDLᵀ.  After the
+// multiplicative damping the normal matrix is SPD, so no pivoting is required; a
+// non-positive pivot reports failure instead of producing garbage.
+template <int N>
+inline bool SolveLdlt(const double* A, const double* b, double* x) {
+#ifdef NOS_HAVE_EIGEN
+  using Mat = Eigen::Matrix<double, N, N, Eigen::RowMajor>;
+  using Vec = Eigen::Matrix<double, N, 1>;
+  Eigen::Map<const Mat> Am(A);
+  Eigen::Map<const Vec> bm(b);
+  Eigen::Map<Vec> xm(x);
+  xm = Am.ldlt().solve(bm);
+  return xm.allFinite();
+#else
+  double L[N][N] = {};
+  double D[N];
+  for (int j = 0; j < N; ++j) {
+    double d = A[N * j + j];
+    for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k] * D[k];
+    if (!(d > 0.0) || !std::isfinite(d)) return false;
+    D[j] = d;
+    L[j][j] = 1.0;
+    for (int i = j + 1; i < N; ++i) {
+      double v = A[N * i + j];
+      for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k] * D[k];
+      L[i][j] = v / d;
+    }
+  }
+  double y[N];
+  for (int i = 0; i < N; ++i) {
+    double v = b[i];
+    for (int k = 0; k < i; ++k) v -= L[i][k] * y[k];
+    y[i] = v;
+  }
+  for (int i = 0; i < N; ++i) y[i] /= D[i];
+  for (int i = N - 1; i >= 0; --i) {
+    double v = y[i];
+    for (int k = i + 1; k < N; ++k) v -= L[k][i] * x[k];
+    x[i] = v;
+  }
+  return true;
+#endif
+}
+
+// out = {upper triangle row-major | gradient | cost}  →  damped step  δ = -(H∘(1+λ on diag))⁻¹ g
+template <int N>
+inline bool DampedStep(const double* out, double lambda, double* step) {
+  double H[N * N], mg[N];
+  int k = 0;
+  for (int r = 0; r < N; ++r)
+    for (int c = r; c < N; ++c) {
+      H[N * r + c] = out[k];
+      H[N * c + r] = out[k];
+      ++k;
+    }
+  for (int r = 0; r < N; ++r) H[N * r + r] *= 1.0 + lambda;
+  for (int r = 0; r < N; ++r) mg[r] = -out[k + r];
+  return SolveLdlt<N>(H, mg, step);
+}
+
+template <int N>
+inline double Norm(const double* v) {
+  double s = 0.0;
+  for (int i = 0; i < N; ++i) s += v[i] * v[i];
+  return std::sqrt(s);
+}
+
+struct LmSettings {
+  int max_iterations = 40;
+  double gradient_tolerance = 1e-6;
+  double parameter_tolerance = 1e-6;
+};
+
+struct LmReport {
+  int iterations = 0;            // loop index at exit: the "iter:" of the reference's stderr line
+  double printed_cost = 0.0;     // previous_cost at exit: the "COST:" of that line
+  double last_cost = 0.0;
+  double final_lambda = 0.0;
+  bool ok = true;                // false if an accumulate call or the 6x6 solve failed
+};
+
+constexpr double kMinLambda = 1e-6;  // constexpr in the reference too (…_analytic_simd.cc:30-31),
+constexpr double kMaxLambda = 1e-2;  // not Options::optimization_handle
+
+// 6-DoF loop.  `accumulate(R, t, out28)` returns false on failure.
+template <typename Accumulate>
+inline LmReport RunLm6(const LmSettings& s, Accumulate&& accumulate, double t[3], double R[9]) {
+  LmReport rep;
+  Quat q = QuatFromMatrix(R);
+  double lambda = 1e-3;
+  double previous_cost = std::numeric_limits<double>::max();
+  double cost = 0.0;
+  int it = 0;
+  for (; it < s.max_iterations; ++it) {
+    double Rc[9], out[28], step[6];
+    QuatToMatrix(q, Rc);
+    if (!accumulate(Rc, t, out)) {
+      rep.ok = false;
+      break;
+    }
+    cost = out[27];
+    if (!DampedStep<6>(out, lambda, step)) {
+      rep.ok = false;
+      break;
+    }
+    t[0] += step[0];
+    t[1] += step[1];
+    t[2] += step[2];
+    RightMultiplyNormalize(&q, ExpQuat(step + 3));
+    if (Norm<6>(step) < s.parameter_tolerance) break;
+    if (Norm<6>(out + 21) < s.gradient_tolerance) break;
+    lambda = std::clamp(lambda * (cost > previous_cost ? 2.0 : 0.6), kMinLambda, kMaxLambda);
+    previous_cost = cost;
+  }
+  QuatToMatrix(q, R);
+  rep.iterations = it;
+  rep.printed_cost = previous_cost;
+  rep.last_cost = cost;
+  rep.final_lambda = lambda;
+  return rep;
+}
+
+// Planar loop: state is the 2x2 rotation (row-major) and (x, y).
+// `accumulate(R2, t2, out10)`.
+template <typename Accumulate>
+inline LmReport RunLm3(const LmSettings& s, Accumulate&& accumulate, double t2[2], double R2[4]) {
+  LmReport rep;
+  double lambda = 1e-3;
+  double previous_cost = std::numeric_limits<double>::max();
+  double cost = 0.0;
+  int it = 0;
+  for (; it < s.max_iterations; ++it) {
+    double out[10], step[3];
+    if (!accumulate(R2, t2, out)) {
+      rep.ok = false;
+      break;
+    }
+    cost = out[9];
+    if (!DampedStep<3>(out, lambda, step)) {
+      rep.ok = false;
+      break;
+    }
+    t2[0] += step[0];
+    t2[1] += step[1];
+    const double c = std::cos(step[2]), sn = std::sin(step[2]);
+    const double a = R2[0], b = R2[1], d = R2[2], e = R2[3];
+    R2[0] = a * c + b * sn;  // linear ← linear · Rot2(δθ)   (Isometry2d::rotate)
+    R2[1] = b * c - a * sn;
+    R2[2] = d * c + e * sn;
+    R2[3] = e * c - d * sn;
+    if (Norm<3>(step) < s.parameter_tolerance) break;
+    if (Norm<3>(out + 6) < s.gradient_tolerance) break;
+    lambda = std::clamp(lambda * (cost > previous_cost ? 2.0 : 0.6), kMinLambda, kMaxLambda);
+    previous_cost = cost;
+  }
+  rep.iterations = it;
+  rep.printed_cost = previous_cost;
+  rep.last_cost = cost;
+  rep.final_lambda = lambda;
+  return rep;
+}
+
+}  // namespace nos_host
+
+#endif  // NOS_LM_HPP_

@@ -1,0 +1,900 @@
+// nos_capi.hip — host side of the C ABI declared in include/nos.h.
+//
+// Owns contexts (per-device stream + workspaces), device-resident tiled-SoA datasets and
+// the launch logic around the kernels in assemble_kernels.hpp.  There is no CPU fallback:
+// without a usable HIP device every entry point fails with NOS_ERR_NO_DEVICE / NOS_ERR_HIP.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/nos.h"
+#include "assemble_kernels.hpp"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int status, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return status;
+}
+
+#define NOS_HIP_CHECK(expr)                                                               \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess)                                                                 \
+      return fail(e_ == hipErrorOutOfMemory ? NOS_ERR_OUT_OF_MEMORY : NOS_ERR_HIP,        \
+                  "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+enum DatasetKind { kKindNdt = 1, kKindReproj = 2 };
+
+constexpr int kMaxPartialRows = 8192;  // upper bound on grid size of the assemble kernel
+constexpr int kMaxOut = 28;
+
+struct DeviceSlot {
+  int device = 0;
+  int num_cus = 256;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;    // own_stream or an external one
+  double* partials = nullptr;      // [kMaxPartialRows][kMaxOut] device
+  double* d_out = nullptr;         // [kMaxOut] device
+  double* h_out = nullptr;         // [kMaxOut] pinned host
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+};
+
+}  // namespace
+
+struct nos_ctx {
+  std::vector<DeviceSlot> slots;
+  int blocks_per_cu = 0;  // 0 = default
+  int variant = 0;        // 0 = default; tuning knob (see pick_variant)
+  int tile_log2 = -1;     // -1 = default; 0 = planar
+};
+
+namespace {
+
+struct Shard {
+  int slot = 0;
+  nos::TiledLayout layout{};
+  void* data = nullptr;
+  size_t bytes = 0;
+};
+
+}  // namespace
+
+struct nos_dataset {
+  nos_ctx* ctx = nullptr;
+  int kind = 0;
+  int dtype = NOS_F64;
+  int n_fields = 0;
+  size_t n = 0;
+  size_t tile = 0;
+  std::vector<Shard> shards;
+};
+
+namespace {
+
+constexpr size_t kDefaultTileLog2 = 12;  // 4096 correspondences per tile
+
+size_t elem_size(int dtype) { return dtype == NOS_F32 ? sizeof(float) : sizeof(double); }
+
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  if (!v || !*v) return dflt;
+  return atoi(v);
+}
+
+// ------------------------------------------------------------------ layout
+
+nos::TiledLayout make_layout(size_t n, int n_fields, int tile_log2) {
+  nos::TiledLayout L{};
+  L.n = n;
+  if (tile_log2 <= 0) {
+    // planar: pad to the largest chunk any kernel variant uses
+    const size_t pad = 4096;
+    L.n_padded = ((n + pad - 1) / pad) * pad;
+    if (L.n_padded == 0) L.n_padded = pad;
+    L.tile_stride = 0;
+    L.field_stride = L.n_padded;
+    L.tile_shift = 40;
+    L.tile_mask = 0xFFFFFFFFu;
+  } else {
+    const size_t tile = size_t(1) << tile_log2;
+    L.n_padded = ((n + tile - 1) / tile) * tile;
+    if (L.n_padded == 0) L.n_padded = tile;
+    L.tile_stride = tile * size_t(n_fields);
+    L.field_stride = tile;
+    L.tile_shift = uint32_t(tile_log2);
+    L.tile_mask = uint32_t(tile - 1);
+  }
+  return L;
+}
+
+size_t layout_elems(const nos::TiledLayout& L, int n_fields) { return L.n_padded * size_t(n_fields); }
+
+// ------------------------------------------------------------------ launch variants
+
+// Number of compiled geometry variants per dtype (see the NOS_CASE tables below; index 0
+// is the default).
+constexpr int kNumVariants = 5;
+
+template <typename Problem, typename T, int ITEMS, int BLOCK, int MINW>
+int launch_variant(const nos::TiledLayout& L, const typename Problem::Params& P, int grid_cap,
+                   bool nt, double* partials, hipStream_t stream, int* rows_out) {
+  constexpr uint32_t kChunk = BLOCK * ITEMS;
+  if (L.n_padded % kChunk != 0) return fail(NOS_ERR_INVALID_ARGUMENT, "n_padded %% chunk != 0");
+  if (L.tile_stride != 0 && ((size_t(L.tile_mask) + 1) % kChunk) != 0)
+    return fail(NOS_ERR_INVALID_ARGUMENT, "tile not a multiple of the kernel chunk");
+  const uint64_t n_chunks64 = L.n_padded / kChunk;
+  if (n_chunks64 > 0xFFFFFFFFull) return fail(NOS_ERR_UNSUPPORTED, "dataset too large for one shard");
+  const uint32_t n_chunks = uint32_t(n_chunks64);
+  int grid = int(std::min<uint64_t>(n_chunks, uint64_t(grid_cap)));
+  if (grid < 1) grid = 1;
+  if (grid > kMaxPartialRows) grid = kMaxPartialRows;
+  if (nt)
+    hipLaunchKernelGGL((nos::assemble_kernel<Problem, T, ITEMS, BLOCK, MINW, true>), dim3(grid), dim3(BLOCK), 0,
+                       stream, L, P, n_chunks, partials);
+  else
+    hipLaunchKernelGGL((nos::assemble_kernel<Problem, T, ITEMS, BLOCK, MINW, false>), dim3(grid), dim3(BLOCK), 0,
+                       stream, L, P, n_chunks, partials);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(NOS_ERR_HIP, "assemble launch failed: %s", hipGetErrorString(e));
+  *rows_out = grid;
+  return NOS_OK;
+}
+
+template <typename Problem, typename T>
+int launch_by_variant(int variant, int blocks_per_cu, int num_cus, const nos::TiledLayout& L,
+                      const typename Problem::Params& P, bool nt, double* partials,
+                      hipStream_t stream, int* rows_out) {
+  if (variant < 0 || variant >= kNumVariants) variant = 0;
+#define NOS_CASE(idx, ITEMS_, BLOCK_, MINW_)                                                        \
+  case idx: {                                                                                       \
+    const int bpc = blocks_per_cu > 0 ? blocks_per_cu : std::max(1, (MINW_ * 256) / BLOCK_);        \
+    return launch_variant<Problem, T, ITEMS_, BLOCK_, MINW_>(L, P, bpc * num_cus, nt, partials, stream, \
+                                                             rows_out);                             \
+  }
+  if constexpr (sizeof(T) == 8) {
+    switch (variant) {
+      NOS_CASE(0, 2, 256, 2)
+      NOS_CASE(1, 1, 256, 3)
+      NOS_CASE(2, 1, 256, 2)
+      NOS_CASE(3, 2, 512, 2)
+      NOS_CASE(4, 1, 512, 3)
+    }
+  } else {
+    switch (variant) {
+      NOS_CASE(0, 4, 256, 2)
+      NOS_CASE(1, 2, 256, 4)
+      NOS_CASE(2, 4, 512, 2)
+      NOS_CASE(3, 1, 256, 4)
+      NOS_CASE(4, 2, 256, 5)
+    }
+  }
+#undef NOS_CASE
+  return fail(NOS_ERR_INVALID_ARGUMENT, "bad variant");
+}
+
+template <template <typename, int> class ProblemT, typename T, typename ParamsT>
+int launch_by_loss(int loss_kind, int variant, int blocks_per_cu, int num_cus,
+                   const nos::TiledLayout& L, const ParamsT& P, bool nt, double* partials,
+                   hipStream_t stream, int* rows_out) {
+  switch (loss_kind) {
+    case NOS_LOSS_NONE:
+      return launch_by_variant<ProblemT<T, nos::kLossNone>, T>(variant, blocks_per_cu, num_cus, L, P, nt, partials,
+                                                               stream, rows_out);
+    case NOS_LOSS_EXPONENTIAL:
+      return launch_by_variant<ProblemT<T, nos::kLossExponential>, T>(variant, blocks_per_cu, num_cus, L, P, nt,
+                                                                      partials, stream, rows_out);
+    case NOS_LOSS_HUBER:
+      return launch_by_variant<ProblemT<T, nos::kLossHuber>, T>(variant, blocks_per_cu, num_cus, L, P, nt, partials,
+                                                                stream, rows_out);
+  }
+  return fail(NOS_ERR_INVALID_ARGUMENT, "unknown loss kind %d", loss_kind);
+}
+
+template <typename T>
+void fill_loss(const nos_loss* loss, T& la, T& lb, T& lc) {
+  la = lb = lc = T(0);
+  if (!loss) return;
+  if (loss->kind == NOS_LOSS_EXPONENTIAL) {
+    la = T(loss->a);
+    lb = T(loss->b);
+    lc = T(2.0 * loss->a * loss->b);
+  } else if (loss->kind == NOS_LOSS_HUBER) {
+    la = T(loss->a);
+    lb = T(loss->a * loss->a);
+    lc = T(2.0 * loss->a);
+  }
+}
+
+int check_loss(const nos_loss* loss, int* kind_out) {
+  int kind = loss ? loss->kind : NOS_LOSS_NONE;
+  if (kind < NOS_LOSS_NONE || kind > NOS_LOSS_HUBER) return fail(NOS_ERR_INVALID_ARGUMENT, "unknown loss kind %d", kind);
+  // same argument checks as the reference constructors (loss_function.h:24-25, 53-54)
+  if (kind == NOS_LOSS_EXPONENTIAL && (loss->a < 0.0 || loss->b < 0.0))
+    return fail(NOS_ERR_INVALID_ARGUMENT, "exponential loss needs c1 >= 0 and c2 >= 0");
+  if (kind == NOS_LOSS_HUBER && !(loss->a > 0.0)) return fail(NOS_ERR_INVALID_ARGUMENT, "huber loss needs threshold > 0");
+  *kind_out = kind;
+  return NOS_OK;
+}
+
+// What one accumulate call computes; POD so the same code path serves all three problems.
+struct Request {
+  int problem;  // 6, 3, 2 (reprojection)
+  double R[9];
+  double t[3];
+  double intr[4];
+  double min_depth;
+  nos_loss loss;
+  int loss_kind;
+  int n_out;
+};
+
+// Streaming (non-temporal) loads when the shard cannot stay resident in the 256 MiB
+// Infinity Cache between iterations; default-policy loads when it can.
+bool use_nontemporal(const nos_dataset* ds, const Shard& sh) {
+  const int force = env_int("NOS_NT", -1);
+  if (force >= 0) return force != 0;
+  (void)ds;
+  return sh.bytes > (size_t(192) << 20);
+}
+
+int launch_assemble(const nos_dataset* ds, const Shard& sh, const Request& rq, double* partials,
+                    hipStream_t stream, int* rows_out) {
+  const nos_ctx* ctx = ds->ctx;
+  const DeviceSlot& slot = ctx->slots[sh.slot];
+  const bool nt = use_nontemporal(ds, sh);
+  const int variant = ctx->variant;
+  const int bpc = ctx->blocks_per_cu;
+  if (rq.problem == 6) {
+    if (ds->dtype == NOS_F64) {
+      nos::Ndt6Params<double> P;
+      for (int k = 0; k < 9; ++k) P.R[k] = rq.R[k];
+      for (int k = 0; k < 3; ++k) P.t[k] = rq.t[k];
+      fill_loss(&rq.loss, P.la, P.lb, P.lc);
+      return launch_by_loss<nos::Ndt6Problem, double>(rq.loss_kind, variant, bpc, slot.num_cus, sh.layout, P, nt,
+                                                      partials, stream, rows_out);
+    }
+    nos::Ndt6Params<float> P;
+    for (int k = 0; k < 9; ++k) P.R[k] = float(rq.R[k]);
+    for (int k = 0; k < 3; ++k) P.t[k] = float(rq.t[k]);
+    fill_loss(&rq.loss, P.la, P.lb, P.lc);
+    return launch_by_loss<nos::Ndt6Problem, float>(rq.loss_kind, variant, bpc, slot.num_cus, sh.layout, P, nt,
+                                                   partials, stream, rows_out);
+  }
+  if (rq.problem == 3) {
+    if (ds->dtype == NOS_F64) {
+      nos::Ndt3Params<double> P;
+      for (int k = 0; k < 4; ++k) P.R2[k] = rq.R[k];
+      for (int k = 0; k < 2; ++k) P.t2[k] = rq.t[k];
+      fill_loss(&rq.loss, P.la, P.lb, P.lc);
+      return launch_by_loss<nos::Ndt3Problem, double>(rq.loss_kind, variant, bpc, slot.num_cus, sh.layout, P, nt,
+                                                      partials, stream, rows_out);
+    }
+    nos::Ndt3Params<float> P;
+    for (int k = 0; k < 4; ++k) P.R2[k] = float(rq.R[k]);
+    for (int k = 0; k < 2; ++k) P.t2[k] = float(rq.t[k]);
+    fill_loss(&rq.loss, P.la, P.lb, P.lc);
+    return launch_by_loss<nos::Ndt3Problem, float>(rq.loss_kind, variant, bpc, slot.num_cus, sh.layout, P, nt,
+                                                   partials, stream, rows_out);
+  }
+  if (ds->dtype == NOS_F64) {
+    nos::ReprojParams<double> P;
+    for (int k = 0; k < 9; ++k) P.R[k] = rq.R[k];
+    for (int k = 0; k < 3; ++k) P.t[k] = rq.t[k];
+    P.inv_fx = rq.intr[0];
+    P.inv_fy = rq.intr[1];
+    P.cx = rq.intr[2];
+    P.cy = rq.intr[3];
+    P.min_depth = rq.min_depth;
+    fill_loss(&rq.loss, P.la, P.lb, P.lc);
+    return launch_by_loss<nos::ReprojProblem, double>(rq.loss_kind, variant, bpc, slot.num_cus, sh.layout, P, nt,
+                                                      partials, stream, rows_out);
+  }
+  nos::ReprojParams<float> P;
+  for (int k = 0; k < 9; ++k) P.R[k] = float(rq.R[k]);
+  for (int k = 0; k < 3; ++k) P.t[k] = float(rq.t[k]);
+  P.inv_fx = float(rq.intr[0]);
+  P.inv_fy = float(rq.intr[1]);
+  P.cx = float(rq.intr[2]);
+  P.cy = float(rq.intr[3]);
+  P.min_depth = float(rq.min_depth);
+  fill_loss(&rq.loss, P.la, P.lb, P.lc);
+  return launch_by_loss<nos::ReprojProblem, float>(rq.loss_kind, variant, bpc, slot.num_cus, sh.layout, P, nt,
+                                                   partials, stream, rows_out);
+}
+
+int launch_final(int n_out, const double* partials, int rows, double* out, hipStream_t stream) {
+  if (n_out == 28)
+    hipLaunchKernelGGL((nos::final_reduce_kernel<28>), dim3(1), dim3(1024), 0, stream, partials, uint32_t(rows), out);
+  else
+    hipLaunchKernelGGL((nos::final_reduce_kernel<10>), dim3(1), dim3(1024), 0, stream, partials, uint32_t(rows), out);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(NOS_ERR_HIP, "final reduce launch failed: %s", hipGetErrorString(e));
+  return NOS_OK;
+}
+
+int build_request(int problem, const nos_dataset* ds, const double* R, int nR, const double* t, int nt,
+                  const double* intr, double min_depth, const nos_loss* loss, Request* rq) {
+  if (!ds) return fail(NOS_ERR_INVALID_ARGUMENT, "dataset is NULL");
+  if (!R || !t) return fail(NOS_ERR_INVALID_ARGUMENT, "pose pointer is NULL");
+  const int want_kind = (problem == 2) ? kKindReproj : kKindNdt;
+  if (ds->kind != want_kind) return fail(NOS_ERR_WRONG_KIND, "dataset kind does not match the entry point");
+  memset(rq, 0, sizeof *rq);
+  rq->problem = problem;
+  for (int k = 0; k < nR; ++k) rq->R[k] = R[k];
+  for (int k = 0; k < nt; ++k) rq->t[k] = t[k];
+  if (problem == 2) {
+    if (!intr) return fail(NOS_ERR_INVALID_ARGUMENT, "intrinsics pointer is NULL");
+    for (int k = 0; k < 4; ++k) rq->intr[k] = intr[k];
+    rq->min_depth = min_depth;
+  }
+  int kind = 0;
+  int rc = check_loss(loss, &kind);
+  if (rc != NOS_OK) return rc;
+  rq->loss_kind = kind;
+  if (loss) rq->loss = *loss;
+  rq->n_out = (problem == 3) ? 10 : 28;
+  return NOS_OK;
+}
+
+// Blocking accumulate over every shard; shard sums are added on the host in shard order
+// (the reference sums its per-thread partials the same way).
+int accumulate_sync(nos_dataset* ds, const Request& rq, double* out) {
+  nos_ctx* ctx = ds->ctx;
+  for (const Shard& sh : ds->shards) {
+    DeviceSlot& slot = ctx->slots[sh.slot];
+    NOS_HIP_CHECK(hipSetDevice(slot.device));
+    int rows = 0;
+    int rc = launch_assemble(ds, sh, rq, slot.partials, slot.stream, &rows);
+    if (rc != NOS_OK) return rc;
+    rc = launch_final(rq.n_out, slot.partials, rows, slot.d_out, slot.stream);
+    if (rc != NOS_OK) return rc;
+    NOS_HIP_CHECK(hipMemcpyAsync(slot.h_out, slot.d_out, sizeof(double) * rq.n_out, hipMemcpyDeviceToHost, slot.stream));
+  }
+  for (int k = 0; k < rq.n_out; ++k) out[k] = 0.0;
+  for (const Shard& sh : ds->shards) {
+    DeviceSlot& slot = ctx->slots[sh.slot];
+    NOS_HIP_CHECK(hipSetDevice(slot.device));
+    NOS_HIP_CHECK(hipStreamSynchronize(slot.stream));
+    for (int k = 0; k < rq.n_out; ++k) out[k] += slot.h_out[k];
+  }
+  return NOS_OK;
+}
+
+int accumulate_async(nos_dataset* ds, const Request& rq, double* d_out) {
+  if (!d_out) return fail(NOS_ERR_INVALID_ARGUMENT, "d_out is NULL");
+  if (ds->shards.size() != 1) return fail(NOS_ERR_UNSUPPORTED, "async accumulate needs a single-device context");
+  nos_ctx* ctx = ds->ctx;
+  const Shard& sh = ds->shards[0];
+  DeviceSlot& slot = ctx->slots[sh.slot];
+  NOS_HIP_CHECK(hipSetDevice(slot.device));
+  int rows = 0;
+  int rc = launch_assemble(ds, sh, rq, slot.partials, slot.stream, &rows);
+  if (rc != NOS_OK) return rc;
+  return launch_final(rq.n_out, slot.partials, rows, d_out, slot.stream);
+}
+
+int time_kernel(nos_dataset* ds, const Request& rq, int repeats, double* kernel_ms, double* total_ms) {
+  if (repeats < 1) repeats = 1;
+  nos_ctx* ctx = ds->ctx;
+  const Shard& sh = ds->shards[0];
+  DeviceSlot& slot = ctx->slots[sh.slot];
+  NOS_HIP_CHECK(hipSetDevice(slot.device));
+  int rows = 0;
+  // warm-up
+  for (int i = 0; i < 2; ++i) {
+    int rc = launch_assemble(ds, sh, rq, slot.partials, slot.stream, &rows);
+    if (rc != NOS_OK) return rc;
+  }
+  NOS_HIP_CHECK(hipEventRecord(slot.ev0, slot.stream));
+  for (int i = 0; i < repeats; ++i) {
+    int rc = launch_assemble(ds, sh, rq, slot.partials, slot.stream, &rows);
+    if (rc != NOS_OK) return rc;
+  }
+  NOS_HIP_CHECK(hipEventRecord(slot.ev1, slot.stream));
+  for (int i = 0; i < repeats; ++i) {
+    int rc = launch_assemble(ds, sh, rq, slot.partials, slot.stream, &rows);
+    if (rc != NOS_OK) return rc;
+    rc = launch_final(rq.n_out, slot.partials, rows, slot.d_out, slot.stream);
+    if (rc != NOS_OK) return rc;
+  }
+  NOS_HIP_CHECK(hipEventRecord(slot.ev2, slot.stream));
+  NOS_HIP_CHECK(hipEventSynchronize(slot.ev2));
+  float ms01 = 0.f, ms12 = 0.f;
+  NOS_HIP_CHECK(hipEventElapsedTime(&ms01, slot.ev0, slot.ev1));
+  NOS_HIP_CHECK(hipEventElapsedTime(&ms12, slot.ev1, slot.ev2));
+  if (kernel_ms) *kernel_ms = double(ms01) / repeats;
+  if (total_ms) *total_ms = double(ms12) / repeats;
+  return NOS_OK;
+}
+
+// ------------------------------------------------------------------ dataset construction
+
+int alloc_shards(nos_ctx* ctx, nos_dataset* ds) {
+  const int n_shards = int(ctx->slots.size());
+  const size_t n = ds->n;
+  const size_t per = (n + n_shards - 1) / size_t(n_shards);  // contiguous equal ranges
+  int tile_log2 = ctx->tile_log2 >= 0 ? ctx->tile_log2 : env_int("NOS_TILE_LOG2", int(kDefaultTileLog2));
+  if (tile_log2 != 0 && (tile_log2 < 10 || tile_log2 > 24)) return fail(NOS_ERR_INVALID_ARGUMENT, "tile_log2 out of range");
+  ds->tile = tile_log2 > 0 ? (size_t(1) << tile_log2) : 0;
+  ds->shards.resize(n_shards);
+  size_t begin = 0;
+  for (int s = 0; s < n_shards; ++s) {
+    const size_t cnt = begin < n ? std::min(per, n - begin) : 0;
+    Shard& sh = ds->shards[s];
+    sh.slot = s;
+    sh.layout = make_layout(cnt, ds->n_fields, tile_log2);
+    sh.bytes = layout_elems(sh.layout, ds->n_fields) * elem_size(ds->dtype);
+    NOS_HIP_CHECK(hipSetDevice(ctx->slots[s].device));
+    NOS_HIP_CHECK(hipMalloc(&sh.data, sh.bytes));
+    sh.layout.base = sh.data;
+    begin += cnt;
+  }
+  return NOS_OK;
+}
+
+template <typename SRC>
+int retile_dispatch(const nos::PlanePtrs& src, int n_fields, const nos::TiledLayout& L, void* dst, int dtype,
+                    hipStream_t stream) {
+  dim3 grid(unsigned((L.n_padded + 255) / 256), unsigned(n_fields));
+  if (dtype == NOS_F64)
+    hipLaunchKernelGGL((nos::retile_kernel<SRC, double>), grid, dim3(256), 0, stream, src, n_fields, L,
+                       static_cast<double*>(dst));
+  else
+    hipLaunchKernelGGL((nos::retile_kernel<SRC, float>), grid, dim3(256), 0, stream, src, n_fields, L,
+                       static_cast<float*>(dst));
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(NOS_ERR_HIP, "retile launch failed: %s", hipGetErrorString(e));
+  return NOS_OK;
+}
+
+int dataset_new(nos_ctx* ctx, int kind, size_t n, int dtype, nos_dataset** out, nos_dataset** made) {
+  if (!ctx || !out) return fail(NOS_ERR_INVALID_ARGUMENT, "ctx / out pointer is NULL");
+  if (dtype != NOS_F64 && dtype != NOS_F32) return fail(NOS_ERR_INVALID_ARGUMENT, "unknown dtype %d", dtype);
+  *out = nullptr;
+  nos_dataset* ds = new (std::nothrow) nos_dataset();
+  if (!ds) return fail(NOS_ERR_OUT_OF_MEMORY, "host allocation failed");
+  ds->ctx = ctx;
+  ds->kind = kind;
+  ds->dtype = dtype;
+  ds->n_fields = (kind == kKindNdt) ? NOS_NDT_PLANES : NOS_REPROJ_PLANES;
+  ds->n = n;
+  int rc = alloc_shards(ctx, ds);
+  if (rc != NOS_OK) {
+    nos_dataset_destroy(ds);
+    return rc;
+  }
+  *made = ds;
+  return NOS_OK;
+}
+
+int create_from_host_planes(nos_ctx* ctx, int kind, size_t n, const double* const* planes, int dtype,
+                            nos_dataset** out) {
+  if (!planes) return fail(NOS_ERR_INVALID_ARGUMENT, "planes is NULL");
+  nos_dataset* ds = nullptr;
+  int rc = dataset_new(ctx, kind, n, dtype, out, &ds);
+  if (rc != NOS_OK) return rc;
+  for (int f = 0; f < ds->n_fields; ++f)
+    if (!planes[f] && n > 0) {
+      nos_dataset_destroy(ds);
+      return fail(NOS_ERR_INVALID_ARGUMENT, "plane %d is NULL", f);
+    }
+  size_t begin = 0;
+  for (Shard& sh : ds->shards) {
+    DeviceSlot& slot = ctx->slots[sh.slot];
+    const size_t cnt = sh.layout.n;
+    hipError_t e = hipSetDevice(slot.device);
+    void* staging = nullptr;
+    const size_t plane_bytes = cnt * sizeof(double);
+    if (e == hipSuccess && cnt > 0) e = hipMalloc(&staging, plane_bytes * ds->n_fields);
+    nos::PlanePtrs src{};
+    for (int f = 0; f < ds->n_fields && e == hipSuccess && cnt > 0; ++f) {
+      char* d = static_cast<char*>(staging) + plane_bytes * f;
+      e = hipMemcpyAsync(d, planes[f] + begin, plane_bytes, hipMemcpyHostToDevice, slot.stream);
+      src.p[f] = d;
+    }
+    if (e == hipSuccess) {
+      rc = retile_dispatch<double>(src, ds->n_fields, sh.layout, sh.data, dtype, slot.stream);
+      if (rc == NOS_OK) e = hipStreamSynchronize(slot.stream);
+    }
+    if (staging) (void)hipFree(staging);
+    if (e != hipSuccess || rc != NOS_OK) {
+      nos_dataset_destroy(ds);
+      if (rc != NOS_OK) return rc;
+      return fail(e == hipErrorOutOfMemory ? NOS_ERR_OUT_OF_MEMORY : NOS_ERR_HIP, "dataset upload failed: %s",
+                  hipGetErrorString(e));
+    }
+    begin += cnt;
+  }
+  *out = ds;
+  return NOS_OK;
+}
+
+int create_from_device_planes(nos_ctx* ctx, int kind, size_t n, const void* const* d_planes, int src_dtype,
+                              int dtype, nos_dataset** out) {
+  if (!d_planes) return fail(NOS_ERR_INVALID_ARGUMENT, "d_planes is NULL");
+  if (!ctx || ctx->slots.size() != 1) return fail(NOS_ERR_UNSUPPORTED, "from_device needs a single-device context");
+  if (src_dtype != NOS_F64 && src_dtype != NOS_F32) return fail(NOS_ERR_INVALID_ARGUMENT, "unknown src dtype");
+  nos_dataset* ds = nullptr;
+  int rc = dataset_new(ctx, kind, n, dtype, out, &ds);
+  if (rc != NOS_OK) return rc;
+  Shard& sh = ds->shards[0];
+  DeviceSlot& slot = ctx->slots[0];
+  nos::PlanePtrs src{};
+  for (int f = 0; f < ds->n_fields; ++f) {
+    if (!d_planes[f] && n > 0) {
+      nos_dataset_destroy(ds);
+      return fail(NOS_ERR_INVALID_ARGUMENT, "device plane %d is NULL", f);
+    }
+    src.p[f] = d_planes[f];
+  }
+  rc = (src_dtype == NOS_F64) ? retile_dispatch<double>(src, ds->n_fields, sh.layout, sh.data, dtype, slot.stream)
+                              : retile_dispatch<float>(src, ds->n_fields, sh.layout, sh.data, dtype, slot.stream);
+  hipError_t e = (rc == NOS_OK) ? hipStreamSynchronize(slot.stream) : hipSuccess;
+  if (rc != NOS_OK || e != hipSuccess) {
+    nos_dataset_destroy(ds);
+    if (rc != NOS_OK) return rc;
+    return fail(NOS_ERR_HIP, "retile failed: %s", hipGetErrorString(e));
+  }
+  *out = ds;
+  return NOS_OK;
+}
+
+template <typename DST>
+int unpack_launch(const unsigned char* d_rec, size_t stride, const nos::FieldOffsets& fo, int n_fields, size_t first,
+                  size_t count, const nos::TiledLayout& L, void* dst, hipStream_t stream) {
+  hipLaunchKernelGGL((nos::unpack_records_kernel<DST>), dim3(unsigned((count + 255) / 256)), dim3(256), 0, stream,
+                     d_rec, uint64_t(stride), fo, n_fields, uint64_t(first), uint64_t(count), L,
+                     static_cast<DST*>(dst));
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(NOS_ERR_HIP, "unpack launch failed: %s", hipGetErrorString(e));
+  return NOS_OK;
+}
+
+template <typename DST>
+int zero_pad_launch(int n_fields, const nos::TiledLayout& L, void* dst, hipStream_t stream) {
+  const size_t pads = L.n_padded - L.n;
+  if (pads == 0) return NOS_OK;
+  hipLaunchKernelGGL((nos::zero_pad_kernel<DST>), dim3(unsigned((pads + 255) / 256)), dim3(256), 0, stream, n_fields, L,
+                     static_cast<DST*>(dst));
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(NOS_ERR_HIP, "zero-pad launch failed: %s", hipGetErrorString(e));
+  return NOS_OK;
+}
+
+// AoS ingestion: records are streamed in chunks through two device staging buffers so
+// the H2D copy of chunk k+1 overlaps the unpack kernel of chunk k.
+int create_from_records(nos_ctx* ctx, int kind, size_t n, const void* records, size_t stride,
+                        const size_t* field_offsets, int dtype, nos_dataset** out) {
+  if ((!records && n > 0) || !field_offsets) return fail(NOS_ERR_INVALID_ARGUMENT, "records / offsets is NULL");
+  nos_dataset* ds = nullptr;
+  int rc = dataset_new(ctx, kind, n, dtype, out, &ds);
+  if (rc != NOS_OK) return rc;
+  nos::FieldOffsets fo{};
+  for (int f = 0; f < ds->n_fields; ++f) {
+    if (field_offsets[f] + sizeof(double) > stride || (field_offsets[f] % sizeof(double)) != 0) {
+      nos_dataset_destroy(ds);
+      return fail(NOS_ERR_INVALID_ARGUMENT, "field offset %d out of record / misaligned", f);
+    }
+    fo.off[f] = uint32_t(field_offsets[f]);
+  }
+  if (stride % sizeof(double) != 0) {
+    nos_dataset_destroy(ds);
+    return fail(NOS_ERR_INVALID_ARGUMENT, "record stride must be a multiple of 8");
+  }
+  const size_t chunk_records = std::max<size_t>(1, (size_t(64) << 20) / stride);
+  const unsigned char* host = static_cast<const unsigned char*>(records);
+  size_t begin = 0;
+  for (Shard& sh : ds->shards) {
+    DeviceSlot& slot = ctx->slots[sh.slot];
+    const size_t cnt = sh.layout.n;
+    hipError_t e = hipSetDevice(slot.device);
+    void* stage[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};
+    hipStream_t copy_stream = nullptr;
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking);
+    for (int b = 0; b < 2 && e == hipSuccess; ++b) {
+      e = hipMalloc(&stage[b], chunk_records * stride);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&done[b], hipEventDisableTiming);
+    }
+    hipEvent_t copied = nullptr;
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&copied, hipEventDisableTiming);
+    int buf = 0;
+    bool used[2] = {false, false};
+    for (size_t first = 0; first < cnt && e == hipSuccess && rc == NOS_OK; first += chunk_records, buf ^= 1) {
+      const size_t count = std::min(chunk_records, cnt - first);
+      if (used[buf]) e = hipStreamWaitEvent(copy_stream, done[buf], 0);  // unpack of the previous use finished
+      if (e == hipSuccess)
+        e = hipMemcpyAsync(stage[buf], host + (begin + first) * stride, count * stride, hipMemcpyHostToDevice,
+                           copy_stream);
+      if (e == hipSuccess) e = hipEventRecord(copied, copy_stream);
+      if (e == hipSuccess) e = hipStreamWaitEvent(slot.stream, copied, 0);
+      if (e == hipSuccess) {
+        rc = (dtype == NOS_F64)
+                 ? unpack_launch<double>(static_cast<unsigned char*>(stage[buf]), stride, fo, ds->n_fields, first, count,
+                                         sh.layout, sh.data, slot.stream)
+                 : unpack_launch<float>(static_cast<unsigned char*>(stage[buf]), stride, fo, ds->n_fields, first, count,
+                                        sh.layout, sh.data, slot.stream);
+        if (rc == NOS_OK) e = hipEventRecord(done[buf], slot.stream);
+        used[buf] = true;
+      }
+    }
+    if (e == hipSuccess && rc == NOS_OK)
+      rc = (dtype == NOS_F64) ? zero_pad_launch<double>(ds->n_fields, sh.layout, sh.data, slot.stream)
+                              : zero_pad_launch<float>(ds->n_fields, sh.layout, sh.data, slot.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(slot.stream);
+    if (copy_stream) {
+      (void)hipStreamSynchronize(copy_stream);
+      (void)hipStreamDestroy(copy_stream);
+    }
+    for (int b = 0; b < 2; ++b) {
+      if (stage[b]) (void)hipFree(stage[b]);
+      if (done[b]) (void)hipEventDestroy(done[b]);
+    }
+    if (copied) (void)hipEventDestroy(copied);
+    if (e != hipSuccess || rc != NOS_OK) {
+      nos_dataset_destroy(ds);
+      if (rc != NOS_OK) return rc;
+      return fail(e == hipErrorOutOfMemory ? NOS_ERR_OUT_OF_MEMORY : NOS_ERR_HIP, "record ingestion failed: %s",
+                  hipGetErrorString(e));
+    }
+    begin += cnt;
+  }
+  *out = ds;
+  return NOS_OK;
+}
+
+}  // namespace
+
+// ====================================================================== C ABI
+
+extern "C" {
+
+int nos_ctx_create(const int* device_ids, int n_devices, nos_ctx** out_ctx) {
+  if (!out_ctx) return fail(NOS_ERR_INVALID_ARGUMENT, "out_ctx is NULL");
+  *out_ctx = nullptr;
+  if (n_devices < 1 || n_devices > 64 || !device_ids) return fail(NOS_ERR_INVALID_ARGUMENT, "bad device list");
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count < 1)
+    return fail(NOS_ERR_NO_DEVICE, "no usable HIP device (%s); this library has no CPU fallback",
+                e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+  for (int i = 0; i < n_devices; ++i)
+    if (device_ids[i] < 0 || device_ids[i] >= count)
+      return fail(NOS_ERR_INVALID_ARGUMENT, "device id %d out of range [0,%d)", device_ids[i], count);
+  nos_ctx* ctx = new (std::nothrow) nos_ctx();
+  if (!ctx) return fail(NOS_ERR_OUT_OF_MEMORY, "host allocation failed");
+  ctx->slots.resize(n_devices);
+  ctx->blocks_per_cu = env_int("NOS_BLOCKS_PER_CU", 0);
+  ctx->variant = env_int("NOS_VARIANT", 0);
+  for (int i = 0; i < n_devices; ++i) {
+    DeviceSlot& s = ctx->slots[i];
+    s.device = device_ids[i];
+    hipDeviceProp_t prop;
+    e = hipSetDevice(s.device);
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, s.device);
+    if (e == hipSuccess) {
+      s.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+      e = hipStreamCreateWithFlags(&s.own_stream, hipStreamNonBlocking);
+    }
+    if (e == hipSuccess) e = hipMalloc(&s.partials, sizeof(double) * kMaxPartialRows * kMaxOut);
+    if (e == hipSuccess) e = hipMalloc(&s.d_out, sizeof(double) * kMaxOut);
+    if (e == hipSuccess) e = hipHostMalloc(&s.h_out, sizeof(double) * kMaxOut, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipEventCreate(&s.ev0);
+    if (e == hipSuccess) e = hipEventCreate(&s.ev1);
+    if (e == hipSuccess) e = hipEventCreate(&s.ev2);
+    s.stream = s.own_stream;
+    if (e != hipSuccess) {
+      nos_ctx_destroy(ctx);
+      return fail(e == hipErrorOutOfMemory ? NOS_ERR_OUT_OF_MEMORY : NOS_ERR_HIP, "context setup failed on device %d: %s",
+                  device_ids[i], hipGetErrorString(e));
+    }
+  }
+  *out_ctx = ctx;
+  return NOS_OK;
+}
+
+int nos_ctx_destroy(nos_ctx* ctx) {
+  if (!ctx) return NOS_OK;
+  for (DeviceSlot& s : ctx->slots) {
+    (void)hipSetDevice(s.device);
+    if (s.own_stream) {
+      (void)hipStreamSynchronize(s.own_stream);
+      (void)hipStreamDestroy(s.own_stream);
+    }
+    if (s.partials) (void)hipFree(s.partials);
+    if (s.d_out) (void)hipFree(s.d_out);
+    if (s.h_out) (void)hipHostFree(s.h_out);
+    if (s.ev0) (void)hipEventDestroy(s.ev0);
+    if (s.ev1) (void)hipEventDestroy(s.ev1);
+    if (s.ev2) (void)hipEventDestroy(s.ev2);
+  }
+  delete ctx;
+  return NOS_OK;
+}
+
+int nos_ctx_num_devices(const nos_ctx* ctx) { return ctx ? int(ctx->slots.size()) : 0; }
+
+int nos_ctx_set_stream(nos_ctx* ctx, int shard, void* hip_stream) {
+  if (!ctx || shard < 0 || shard >= int(ctx->slots.size())) return fail(NOS_ERR_INVALID_ARGUMENT, "bad ctx / shard");
+  ctx->slots[shard].stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->slots[shard].own_stream;
+  return NOS_OK;
+}
+
+int nos_ctx_synchronize(nos_ctx* ctx) {
+  if (!ctx) return fail(NOS_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  for (DeviceSlot& s : ctx->slots) {
+    NOS_HIP_CHECK(hipSetDevice(s.device));
+    NOS_HIP_CHECK(hipStreamSynchronize(s.stream));
+  }
+  return NOS_OK;
+}
+
+int nos_ctx_set_launch(nos_ctx* ctx, int blocks_per_cu, int variant) {
+  if (!ctx) return fail(NOS_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  if (blocks_per_cu < 0 || blocks_per_cu > 32 || variant < 0 || variant >= kNumVariants)
+    return fail(NOS_ERR_INVALID_ARGUMENT, "launch override out of range");
+  ctx->blocks_per_cu = blocks_per_cu;
+  ctx->variant = variant;
+  return NOS_OK;
+}
+
+int nos_ndt_dataset_create(nos_ctx* ctx, size_t n, const double* const planes[NOS_NDT_PLANES], int dtype,
+                           nos_dataset** out_ds) {
+  return create_from_host_planes(ctx, kKindNdt, n, planes, dtype, out_ds);
+}
+
+int nos_reproj_dataset_create(nos_ctx* ctx, size_t n, const double* const planes[NOS_REPROJ_PLANES], int dtype,
+                              nos_dataset** out_ds) {
+  return create_from_host_planes(ctx, kKindReproj, n, planes, dtype, out_ds);
+}
+
+int nos_ndt_dataset_create_from_device(nos_ctx* ctx, size_t n, const void* const d_planes[NOS_NDT_PLANES],
+                                       int src_dtype, int dtype, nos_dataset** out_ds) {
+  return create_from_device_planes(ctx, kKindNdt, n, d_planes, src_dtype, dtype, out_ds);
+}
+
+int nos_reproj_dataset_create_from_device(nos_ctx* ctx, size_t n, const void* const d_planes[NOS_REPROJ_PLANES],
+                                          int src_dtype, int dtype, nos_dataset** out_ds) {
+  return create_from_device_planes(ctx, kKindReproj, n, d_planes, src_dtype, dtype, out_ds);
+}
+
+int nos_ndt_dataset_create_from_records(nos_ctx* ctx, size_t n, const void* records, size_t stride_bytes,
+                                        const size_t field_offsets[NOS_NDT_PLANES], int dtype,
+                                        nos_dataset** out_ds) {
+  return create_from_records(ctx, kKindNdt, n, records, stride_bytes, field_offsets, dtype, out_ds);
+}
+
+int nos_reproj_dataset_create_from_records(nos_ctx* ctx, size_t n, const void* records, size_t stride_bytes,
+                                           const size_t field_offsets[NOS_REPROJ_PLANES], int dtype,
+                                           nos_dataset** out_ds) {
+  return create_from_records(ctx, kKindReproj, n, records, stride_bytes, field_offsets, dtype, out_ds);
+}
+
+int nos_dataset_destroy(nos_dataset* ds) {
+  if (!ds) return NOS_OK;
+  for (Shard& sh : ds->shards) {
+    if (sh.data) {
+      (void)hipSetDevice(ds->ctx->slots[sh.slot].device);
+      (void)hipFree(sh.data);
+    }
+  }
+  delete ds;
+  return NOS_OK;
+}
+
+size_t nos_dataset_size(const nos_dataset* ds) { return ds ? ds->n : 0; }
+int nos_dataset_dtype(const nos_dataset* ds) { return ds ? ds->dtype : -1; }
+size_t nos_dataset_stream_bytes(const nos_dataset* ds) {
+  return ds ? ds->n * size_t(ds->n_fields) * elem_size(ds->dtype) : 0;
+}
+
+int nos_ndt6_accumulate(nos_dataset* ds, const double R[9], const double t[3], const nos_loss* loss,
+                        double out28[NOS_NDT6_OUT]) {
+  Request rq;
+  int rc = build_request(6, ds, R, 9, t, 3, nullptr, 0.0, loss, &rq);
+  if (rc != NOS_OK) return rc;
+  if (!out28) return fail(NOS_ERR_INVALID_ARGUMENT, "out28 is NULL");
+  return accumulate_sync(ds, rq, out28);
+}
+
+int nos_ndt3_accumulate(nos_dataset* ds, const double R2[4], const double t2[2], const nos_loss* loss,
+                        double out10[NOS_NDT3_OUT]) {
+  Request rq;
+  int rc = build_request(3, ds, R2, 4, t2, 2, nullptr, 0.0, loss, &rq);
+  if (rc != NOS_OK) return rc;
+  if (!out10) return fail(NOS_ERR_INVALID_ARGUMENT, "out10 is NULL");
+  return accumulate_sync(ds, rq, out10);
+}
+
+int nos_reproj_accumulate(nos_dataset* ds, const double R[9], const double t[3], const double intr[4],
+                          const nos_loss* loss, double min_depth, double out28[NOS_REPROJ_OUT]) {
+  Request rq;
+  int rc = build_request(2, ds, R, 9, t, 3, intr, min_depth, loss, &rq);
+  if (rc != NOS_OK) return rc;
+  if (!out28) return fail(NOS_ERR_INVALID_ARGUMENT, "out28 is NULL");
+  return accumulate_sync(ds, rq, out28);
+}
+
+int nos_ndt6_accumulate_async(nos_dataset* ds, const double R[9], const double t[3], const nos_loss* loss,
+                              double* d_out28) {
+  Request rq;
+  int rc = build_request(6, ds, R, 9, t, 3, nullptr, 0.0, loss, &rq);
+  if (rc != NOS_OK) return rc;
+  return accumulate_async(ds, rq, d_out28);
+}
+
+int nos_ndt3_accumulate_async(nos_dataset* ds, const double R2[4], const double t2[2], const nos_loss* loss,
+                              double* d_out10) {
+  Request rq;
+  int rc = build_request(3, ds, R2, 4, t2, 2, nullptr, 0.0, loss, &rq);
+  if (rc != NOS_OK) return rc;
+  return accumulate_async(ds, rq, d_out10);
+}
+
+int nos_reproj_accumulate_async(nos_dataset* ds, const double R[9], const double t[3], const double intr[4],
+                                const nos_loss* loss, double min_depth, double* d_out28) {
+  Request rq;
+  int rc = build_request(2, ds, R, 9, t, 3, intr, min_depth, loss, &rq);
+  if (rc != NOS_OK) return rc;
+  return accumulate_async(ds, rq, d_out28);
+}
+
+int nos_ndt6_time_kernel(nos_dataset* ds, const double R[9], const double t[3], const nos_loss* loss, int repeats,
+                         double* kernel_ms, double* total_ms) {
+  Request rq;
+  int rc = build_request(6, ds, R, 9, t, 3, nullptr, 0.0, loss, &rq);
+  if (rc != NOS_OK) return rc;
+  return time_kernel(ds, rq, repeats, kernel_ms, total_ms);
+}
+
+int nos_ndt3_time_kernel(nos_dataset* ds, const double R2[4], const double t2[2], const nos_loss* loss, int repeats,
+                         double* kernel_ms, double* total_ms) {
+  Request rq;
+  int rc = build_request(3, ds, R2, 4, t2, 2, nullptr, 0.0, loss, &rq);
+  if (rc != NOS_OK) return rc;
+  return time_kernel(ds, rq, repeats, kernel_ms, total_ms);
+}
+
+int nos_reproj_time_kernel(nos_dataset* ds, const double R[9], const double t[3], const double intr[4],
+                           const nos_loss* loss, double min_depth, int repeats, double* kernel_ms,
+                           double* total_ms) {
+  Request rq;
+  int rc = build_request(2, ds, R, 9, t, 3, intr, min_depth, loss, &rq);
+  if (rc != NOS_OK) return rc;
+  return time_kernel(ds, rq, repeats, kernel_ms, total_ms);
+}
+
+const char* nos_status_string(int status) {
+  switch (status) {
+    case NOS_OK: return "ok";
+    case NOS_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case NOS_ERR_NO_DEVICE: return "no HIP device (no CPU fallback)";
+    case NOS_ERR_HIP: return "HIP runtime error";
+    case NOS_ERR_OUT_OF_MEMORY: return "out of memory";
+    case NOS_ERR_WRONG_KIND: return "dataset kind mismatch";
+    case NOS_ERR_UNSUPPORTED: return "unsupported";
+  }
+  return "unknown status";
+}
+
+const char* nos_last_error(void) { return g_last_error.c_str(); }
+const char* nos_version(void) { return "nos-hip 0.1 (gfx950)"; }
+
+}  // extern "C"

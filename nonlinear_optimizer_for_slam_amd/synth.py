@@ -1,0 +1,64 @@
+"""Seeded synthetic workloads — wraps csrc/host/nos_synth.cpp.
+
+Host-side test/bench input generation only; no GPU and no oracle involved.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import _lib
+
+SEED = 20250912
+_host = None
+
+
+def host_lib():
+    global _host
+    if _host is None:
+        if not os.path.exists(_lib.LIB_HOST):
+            raise ImportError("libnos_host.so is missing at %s — run `python __graft_entry__.py`" % _lib.LIB_HOST)
+        _lib.hip_lib()  # dependency of libnos_host.so, load it first from its in-tree path
+        _host = ctypes.CDLL(_lib.LIB_HOST)
+        _host.nos_synth_true_pose.restype = None
+        _host.nos_host_sizeof_ndt_correspondence.restype = ctypes.c_size_t
+    return _host
+
+
+def _out_planes(count, n):
+    planes = np.empty((count, n), dtype=np.float64)
+    arr = (_lib.c_double_p * count)(*[planes[k].ctypes.data_as(_lib.c_double_p) for k in range(count)])
+    return planes, arr
+
+
+def ndt_planes(n, n_voxels, seed=SEED, threads=0):
+    """[15, n] float64: point(3), mean(3), sqrt-information(9, row-major)."""
+    planes, arr = _out_planes(15, n)
+    rc = host_lib().nos_synth_ndt(ctypes.c_uint64(seed), ctypes.c_size_t(n), ctypes.c_size_t(n_voxels), arr,
+                                  ctypes.c_int(threads))
+    if rc != 0:
+        raise RuntimeError("nos_synth_ndt failed: %d" % rc)
+    return planes
+
+
+def reproj_planes(n, seed=SEED, threads=0):
+    """[5, n] float64: X, Y, Z, u, v.  Intrinsics: fx = fy = 525, cx = 320, cy = 240."""
+    planes, arr = _out_planes(5, n)
+    rc = host_lib().nos_synth_reproj(ctypes.c_uint64(seed), ctypes.c_size_t(n), arr, ctypes.c_int(threads))
+    if rc != 0:
+        raise RuntimeError("nos_synth_reproj failed: %d" % rc)
+    return planes
+
+
+REPROJ_INTRINSICS = (525.0, 525.0, 320.0, 240.0)           # fx, fy, cx, cy
+REPROJ_INTR4 = (1.0 / 525.0, 1.0 / 525.0, 320.0, 240.0)    # inv_fx, inv_fy, cx, cy (C ABI order)
+REPROJ_HUBER_THRESHOLD = 1.0 / 525.0                        # 1 px in normalised image coordinates
+
+
+def true_pose(which="ndt"):
+    """(R [3,3], t [3]) of the scene's ground truth; reprojection solves for its inverse."""
+    R = np.zeros(9)
+    t = np.zeros(3)
+    host_lib().nos_synth_true_pose(0 if which == "ndt" else 1, R.ctypes.data_as(_lib.c_double_p),
+                                   t.ctypes.data_as(_lib.c_double_p))
+    return R.reshape(3, 3), t

@@ -1,0 +1,287 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on
+identical seeded inputs.  Tolerances (written here, used below):
+
+  fp64 kernels vs fp64 oracle, per-iteration H/g/cost : 1e-10 scaled
+  fp32 kernels vs fp64 oracle                          : 2e-4 scaled  (reference's own fp32-vs-fp64
+                                                         gap is ~1e-5 in the final pose,
+                                                         results/maha_amd64_simple.txt:24-25)
+  final pose, fp64 LM loop                              : 1e-6 (north star), expected ~1e-10
+"""
+import numpy as np
+import pytest
+
+from nonlinear_optimizer_for_slam_amd import NdtDataset, ReprojDataset, Context, solvers, synth
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+RTOL_F64 = 1e-10
+RTOL_F32 = 2e-4
+LOSSES = [None, ("exponential", 1.0, 1.0), ("huber", 1.2)]
+R_TEST = helpers.rot_xyz(0.01, -0.02, 0.05)
+T_TEST = np.array([-0.1, 0.05, 0.2])
+
+
+@pytest.mark.parametrize("n", [1, 63, 1000, 4097, 100_003])
+@pytest.mark.parametrize("loss", LOSSES)
+def test_ndt6_f64_matches_oracle(ctx, oracle, n, loss):
+    planes = synth.ndt_planes(n, max(1, n // 20))
+    ds = NdtDataset.from_planes(ctx, planes, "f64")
+    assert len(ds) == n and ds.stream_bytes == n * 120
+    got = ds.accumulate6(R_TEST, T_TEST, loss)
+    want = oracle.ndt6_accumulate(planes, R_TEST, T_TEST, loss)
+    helpers.assert_normal_equations_close(got, want, 6, RTOL_F64)
+    ds.close()
+
+
+@pytest.mark.parametrize("loss", LOSSES)
+def test_ndt6_f32_matches_oracle_within_fp32(ctx, oracle, loss):
+    planes = synth.ndt_planes(50_000, 2500)
+    ds = NdtDataset.from_planes(ctx, planes, "f32")
+    assert ds.stream_bytes == 50_000 * 60
+    got = ds.accumulate6(R_TEST, T_TEST, loss)
+    want = oracle.ndt6_accumulate(planes, R_TEST, T_TEST, loss)
+    helpers.assert_normal_equations_close(got, want, 6, RTOL_F32)
+    ds.close()
+
+
+@pytest.mark.parametrize("dtype,rtol", [("f64", RTOL_F64), ("f32", RTOL_F32)])
+@pytest.mark.parametrize("loss", LOSSES)
+def test_ndt3_matches_oracle(ctx, oracle, dtype, rtol, loss):
+    planes = synth.ndt_planes(30_001, 1500)
+    c, s = np.cos(0.07), np.sin(0.07)
+    R2 = np.array([[c, -s], [s, c]])
+    t2 = np.array([-0.15, 0.1])
+    ds = NdtDataset.from_planes(ctx, planes, dtype)
+    got = ds.accumulate3(R2, t2, loss)
+    want = oracle.ndt3_accumulate(planes, R2, t2, loss)
+    helpers.assert_normal_equations_close(got, want, 3, rtol)
+    ds.close()
+
+
+@pytest.mark.parametrize("dtype,rtol", [("f64", RTOL_F64), ("f32", 5e-3)])
+@pytest.mark.parametrize("loss", [None, ("exponential", 1.0, 1.0), ("huber", synth.REPROJ_HUBER_THRESHOLD)])
+def test_reproj_matches_oracle(ctx, oracle, dtype, rtol, loss):
+    planes = synth.reproj_planes(40_003)
+    planes[2, :100] = -2.0  # behind the camera → dropped by the depth test (REM/..._analytic.cc:119-123)
+    R = helpers.rot_xyz(0.0, 0.01, -0.08)
+    t = np.array([0.08, -0.1, 0.4])
+    ds = ReprojDataset.from_planes(ctx, planes, dtype)
+    got = ds.accumulate(R, t, synth.REPROJ_INTR4, loss)
+    want = oracle.reproj_accumulate(planes, R, t, synth.REPROJ_INTR4, loss)
+    helpers.assert_normal_equations_close(got, want, 6, rtol)
+    ds.close()
+
+
+def test_empty_dataset_gives_zero_sums(ctx):
+    planes = np.zeros((15, 0))
+    ds = NdtDataset.from_planes(ctx, planes, "f64")
+    out = ds.accumulate6(np.eye(3), np.zeros(3), ("exponential", 1.0, 1.0))
+    assert np.all(out == 0.0)
+    ds.close()
+
+
+def test_repeated_launches_are_bit_identical(ctx):
+    planes = synth.ndt_planes(300_000, 5000)
+    ds = NdtDataset.from_planes(ctx, planes, "f64")
+    a = ds.accumulate6(R_TEST, T_TEST, ("exponential", 1.0, 1.0))
+    for _ in range(3):
+        assert np.array_equal(a, ds.accumulate6(R_TEST, T_TEST, ("exponential", 1.0, 1.0)))
+    ds.close()
+
+
+def test_ingestion_paths_agree_bit_for_bit(ctx):
+    """host planes / device planes (torch) / array-of-structures records → same tiled dataset."""
+    import torch
+    n = 20_011
+    planes = synth.ndt_planes(n, 800)
+    loss = ("exponential", 1.0, 1.0)
+    a = NdtDataset.from_planes(ctx, planes, "f64")
+    want = a.accumulate6(R_TEST, T_TEST, loss)
+    dev = torch.from_numpy(planes).cuda()
+    b = NdtDataset.from_device_planes(ctx, dev, "f64")
+    assert np.array_equal(want, b.accumulate6(R_TEST, T_TEST, loss))
+    # the reference's 304-byte Correspondence (MDM/types.h:11-26) with Eigen's column-major 3x3:
+    # point @0, ndt.mean @128, ndt.sqrt_information @224
+    rec = np.zeros((n, 38), dtype=np.float64)
+    rec[:, 0:3] = planes[0:3].T
+    rec[:, 16:19] = planes[3:6].T
+    offs = [0, 8, 16, 128, 136, 144]
+    for i in range(3):
+        for j in range(3):
+            rec[:, 28 + 3 * j + i] = planes[6 + 3 * i + j]
+            offs.append(224 + 8 * (3 * j + i))
+    offs = offs[:6] + [224 + 8 * (3 * j + i) for i in range(3) for j in range(3)]
+    c = NdtDataset.from_records(ctx, rec, 304, offs, "f64")
+    assert len(c) == n
+    assert np.array_equal(want, c.accumulate6(R_TEST, T_TEST, loss))
+    for d in (a, b, c):
+        d.close()
+
+
+def test_two_shards_on_one_device_match_single_shard(oracle):
+    """Single-process fan-out (context listing the device twice): contiguous shards, host sum."""
+    planes = synth.ndt_planes(70_001, 3000)
+    loss = ("exponential", 1.0, 1.0)
+    c2 = Context((0, 0))
+    ds = NdtDataset.from_planes(c2, planes, "f64")
+    got = ds.accumulate6(R_TEST, T_TEST, loss)
+    want = oracle.ndt6_accumulate(planes, R_TEST, T_TEST, loss)
+    helpers.assert_normal_equations_close(got, want, 6, RTOL_F64)
+    ds.close()
+    c2.close()
+
+
+def test_async_result_in_torch_tensor_matches_sync(ctx):
+    import torch
+    planes = synth.ndt_planes(50_000, 2000)
+    loss = ("exponential", 1.0, 1.0)
+    ds = NdtDataset.from_planes(ctx, planes, "f64")
+    want = ds.accumulate6(R_TEST, T_TEST, loss)
+    out = torch.zeros(28, dtype=torch.float64, device="cuda")
+    ctx.use_torch_stream()
+    ds.accumulate6_async(R_TEST, T_TEST, loss, out)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), want)
+    ctx.set_stream(0)
+    ds.close()
+
+
+def test_every_launch_geometry_gives_the_same_sums(oracle):
+    planes = synth.ndt_planes(123_457, 4000)
+    loss = ("exponential", 1.0, 1.0)
+    want = oracle.ndt6_accumulate(planes, R_TEST, T_TEST, loss)
+    c = Context((0,))
+    for dtype, rtol in (("f64", RTOL_F64), ("f32", RTOL_F32)):
+        ds = NdtDataset.from_planes(c, planes, dtype)
+        for variant in range(5):
+            for bpc in (0, 1, 4):
+                c.set_launch(bpc, variant)
+                helpers.assert_normal_equations_close(ds.accumulate6(R_TEST, T_TEST, loss), want, 6, rtol)
+        ds.close()
+    c.close()
+
+
+# ---------------------------------------------------------------- Solve() through the C++ classes
+
+def test_reprojection_known_answer_on_gpu():
+    """End-to-end golden of the reference (results/reproj_amd64.txt:5,8): ReprojectionErrorMinimizerHip
+    from identity, ExponentialLossFunction(1,1), default Options → `COST: 2.33228e-11, iter: 6`
+    and the true pose."""
+    planes, intr, Rt, tt = helpers.reference_reprojection_scene()
+    solver = solvers.ReprojectionErrorMinimizerHip()
+    solver.SetLossFunction(("exponential", 1.0, 1.0))
+    pose = solvers.Pose()
+    assert solver.Solve(solvers.Options(), planes, intr, pose)
+    assert solver.report.iterations == 6
+    assert "%.5g" % solver.report.printed_cost == "2.3323e-11"
+    inv = pose.inverse()
+    np.testing.assert_allclose(inv.t, tt, atol=5e-7)
+    np.testing.assert_allclose(inv.R, Rt, atol=1e-7)
+
+
+@pytest.mark.parametrize("loss", [("exponential", 1.0, 1.0), None])
+def test_ndt6_solve_matches_oracle_final_pose(oracle, loss):
+    """BASELINE.json configs[0] shape: 100k points / 5k voxels, 6-DoF, default Options."""
+    planes = synth.ndt_planes(100_000, 5000)
+    want = oracle.ndt6_solve(planes, np.zeros(3), np.eye(3), loss=loss, linear_solver=1)
+    solver = solvers.MahalanobisDistanceMinimizerHip()
+    solver.SetLossFunction(loss)
+    pose = solvers.Pose()
+    assert solver.Solve(solvers.Options(), planes, pose)
+    assert solver.report.iterations == want["iterations"]
+    dt, dq = helpers.pose_delta(pose.R, pose.t, want["R"], want["t"])
+    assert dt < 1e-6 and dq < 1e-6, (dt, dq)   # north-star tolerance
+    assert dt < 1e-9 and dq < 1e-9, (dt, dq)   # what fp64 actually delivers
+    Rt, tt = synth.true_pose("ndt")
+    dt, dq = helpers.pose_delta(pose.R, pose.t, Rt, tt)
+    assert dt < 5e-3 and dq < 2e-3
+
+
+def test_ndt6_solve_f32_tracks_fp64_oracle(oracle):
+    planes = synth.ndt_planes(100_000, 5000)
+    loss = ("exponential", 1.0, 1.0)
+    want = oracle.ndt6_solve(planes, np.zeros(3), np.eye(3), loss=loss, linear_solver=1)
+    solver = solvers.MahalanobisDistanceMinimizerHip(dtype="f32")
+    solver.SetLossFunction(loss)
+    pose = solvers.Pose()
+    assert solver.Solve(solvers.Options(), planes, pose)
+    dt, dq = helpers.pose_delta(pose.R, pose.t, want["R"], want["t"])
+    assert dt < 2e-4 and dq < 2e-4, (dt, dq)
+
+
+def test_ndt3_solve_matches_oracle(oracle):
+    planes = synth.ndt_planes(60_000, 3000)
+    want = oracle.ndt3_solve(planes, np.zeros(3), np.eye(3), loss=("exponential", 1.0, 1.0))
+    solver = solvers.MahalanobisDistanceMinimizerHip3DOF()
+    solver.SetLossFunction(("exponential", 1.0, 1.0))
+    pose = solvers.Pose()
+    assert solver.Solve(solvers.Options(), planes, pose)
+    assert solver.report.iterations == want["iterations"]
+    np.testing.assert_allclose(pose.t, want["t"], atol=1e-9)
+    np.testing.assert_allclose(pose.R, want["R"], atol=1e-9)
+
+
+def test_reproj_solve_huber_matches_oracle(oracle):
+    """BASELINE.json configs[2] shape (scaled to 200k): Huber loss, noisy pixels, 5 % outliers."""
+    planes = synth.reproj_planes(200_000)
+    loss = ("huber", synth.REPROJ_HUBER_THRESHOLD)
+    want = oracle.reproj_solve(planes, synth.REPROJ_INTR4, np.zeros(3), np.eye(3), loss=loss, linear_solver=1)
+    solver = solvers.ReprojectionErrorMinimizerHip()
+    solver.SetLossFunction(loss)
+    pose = solvers.Pose()
+    assert solver.Solve(solvers.Options(), planes, synth.REPROJ_INTRINSICS, pose)
+    assert solver.report.iterations == want["iterations"]
+    dt, dq = helpers.pose_delta(pose.R, pose.t, want["R"], want["t"])
+    assert dt < 1e-8 and dq < 1e-8, (dt, dq)
+    Rt, tt = synth.true_pose("reproj")
+    inv = pose.inverse()
+    assert np.max(np.abs(inv.t - tt)) < 2e-3
+
+
+def test_prepared_dataset_resolve_is_repeatable():
+    planes = synth.ndt_planes(50_000, 2500)
+    solver = solvers.MahalanobisDistanceMinimizerHip()
+    solver.SetLossFunction(("exponential", 1.0, 1.0))
+    p1 = solvers.Pose()
+    assert solver.Solve(solvers.Options(), planes, p1)
+    p2 = solvers.Pose()
+    assert solver.Solve(solvers.Options(), planes, p2, repeat_solves=3)
+    assert np.array_equal(p1.t, p2.t) and np.array_equal(p1.R, p2.R)
+
+
+# ---------------------------------------------------------------- full-size properties
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_full_size_additivity_and_permutation(ctx, dtype):
+    """BASELINE.json configs[1] size (10 M points / 200 k voxels), too big for the scalar oracle to
+    be the only check: the sums are additive over any split of the correspondences and invariant
+    under permutation, so   A(all) == A(first part) + A(rest)   and   A(all) == A(reversed)."""
+    n = 10_000_000
+    planes = synth.ndt_planes(n, 200_000)
+    loss = ("exponential", 1.0, 1.0)
+    rtol = 1e-11 if dtype == "f64" else 2e-5
+    whole = NdtDataset.from_planes(ctx, planes, dtype)
+    a_all = whole.accumulate6(R_TEST, T_TEST, loss)
+    whole.close()
+    cut = 3_333_333
+    parts = np.zeros(28)
+    for sl in (slice(0, cut), slice(cut, n)):
+        ds = NdtDataset.from_planes(ctx, np.ascontiguousarray(planes[:, sl]), dtype)
+        parts += ds.accumulate6(R_TEST, T_TEST, loss)
+        ds.close()
+    helpers.assert_normal_equations_close(parts, a_all, 6, rtol)
+    rev = NdtDataset.from_planes(ctx, np.ascontiguousarray(planes[:, ::-1]), dtype)
+    helpers.assert_normal_equations_close(rev.accumulate6(R_TEST, T_TEST, loss), a_all, 6, rtol)
+    rev.close()
+
+
+def test_full_size_sample_against_oracle(ctx, oracle):
+    """A 1 M-correspondence slice of the 10 M workload against the scalar oracle directly."""
+    planes = synth.ndt_planes(1_000_000, 200_000)
+    loss = ("exponential", 1.0, 1.0)
+    ds = NdtDataset.from_planes(ctx, planes, "f64")
+    got = ds.accumulate6(R_TEST, T_TEST, loss)
+    want = oracle.ndt6_accumulate(planes, R_TEST, T_TEST, loss)
+    helpers.assert_normal_equations_close(got, want, 6, RTOL_F64)
+    ds.close()
