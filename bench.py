@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Gauss-Newton / LM iterations of the 6-DoF NDT solver on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" is one full LM iteration of MahalanobisDistanceMinimizer (6-DoF, fp64, robust
+ExponentialLossFunction(1,1)) over the rank's resident correspondences: assemble kernel (residual +
+analytic Jacobian + weight + 28-scalar reduction) → final reduce → [N>1: one RCCL all-reduce of the 28
+doubles] → 224-byte readback → host damping + 6x6 LDLT + pose update + lambda schedule.  The dataset is
+uploaded before the timed region (inputs resident in HBM).
+
+Workload: BASELINE.json configs[1] — 10 M synthetic correspondences over 200 k NDT voxels per GPU
+(weak scaling: configs[3] is 8 x 10 M = 80 M over 8 GPUs), generator of SURVEY.md §8d.
+
+Prints ONE JSON line on rank 0.  `value` = correspondences (3-vector residual blocks) processed per
+second by the whole job; scalar residuals/s = 3x that; GN iterations/s = steps / elapsed.
+"""
+import argparse
+import ctypes
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+HBM_MEASURED_COPY_GBPS = 6290.0  # same guide: measured float4 copy
+BYTES_PER_CORR = {"f64": 120, "f32": 60}  # 15 planes x sizeof(element), SURVEY.md §8d
+N_VOXELS = 200_000
+LOSS = ("exponential", 1.0, 1.0)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--points", type=int, default=10_000_000, help="correspondences per GPU")
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="time budget per CPU baseline leg")
+    return ap.parse_args()
+
+
+def cpu_baseline(planes, seconds):
+    """The reference's CPU paths restated (oracle/), timed on this host: AVX2+FMA fp32 over all
+    cores with the reference's thread partition, and the scalar fp64 class on one core.
+    Runs on rank 0 at N=1 only; the oracle is used here as the thing being TIMED AS A BASELINE,
+    never as part of the GPU path."""
+    from oracle import loader as oracle
+    n = planes.shape[1]
+    R = np.eye(3)
+    t = np.zeros(3)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    p32 = planes.astype(np.float32)
+    oracle.avx_ndt6_accumulate(p32[:, :80_000], R, t, LOSS, threads=cores)  # warm the pool / pages
+    passes, t0 = 0, time.perf_counter()
+    while True:
+        oracle.avx_ndt6_accumulate(p32, R, t, LOSS, threads=cores)
+        passes += 1
+        el = time.perf_counter() - t0
+        if el >= seconds and passes >= 2:
+            break
+    avx = {"value": n * passes / el, "unit": "corr/s", "cores": cores, "kind": "port",
+           "sample": "%d full passes over the same %d-correspondence workload, AVX2+FMA fp32 lanes "
+                     "(restates ..._analytic_simd_various.cc:1300-1447), %d threads, reference thread partition"
+                     % (passes, n, cores)}
+    del p32
+    ns = min(n, 4_000_000)
+    sub = np.ascontiguousarray(planes[:, :ns])
+    passes, t0 = 0, time.perf_counter()
+    while True:
+        oracle.ndt6_accumulate(sub, R, t, LOSS)
+        passes += 1
+        el = time.perf_counter() - t0
+        if el >= seconds and passes >= 2:
+            break
+    scalar = {"value": ns * passes / el, "unit": "corr/s", "cores": 1, "kind": "port",
+              "sample": "%d passes over the first %d correspondences, scalar fp64 "
+                        "(restates ..._analytic.cc:12-52)" % (passes, ns)}
+    return avx, scalar
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    import torch
+    from nonlinear_optimizer_for_slam_amd import Context, NdtDataset, _lib, distributed, solvers, synth
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+
+    n_local = args.points
+    blocks_per_rank = (n_local + 65535) // 65536
+    planes = synth.ndt_planes(n_local, N_VOXELS, first_block=rank * blocks_per_rank)
+    ctx = Context((local_rank,))
+    ds = NdtDataset.from_planes(ctx, planes, args.dtype)
+    if not (rank == 0 and world == 1 and not args.no_cpu_baseline):
+        del planes
+        planes = None
+
+    host = synth.host_lib()
+    loss = solvers.make_loss(LOSS)
+    pose_t = np.zeros(3)
+    pose_R = np.eye(3).reshape(-1).copy()
+    rep = np.zeros(5)
+
+    if world == 1:
+        def iterate(k):
+            ok = host.nos_host_ndt6_iterate(ds._h, ctypes.byref(loss), ctypes.c_int(k),
+                                            pose_t.ctypes.data_as(_lib.c_double_p),
+                                            pose_R.ctypes.data_as(_lib.c_double_p),
+                                            rep.ctypes.data_as(_lib.c_double_p))
+            if not ok or int(rep[0]) != k:
+                raise RuntimeError("LM loop failed: ok=%s iterations=%s status=%s" % (ok, rep[0], rep[4]))
+    else:
+        ctx.use_torch_stream()
+        out = torch.zeros(28, dtype=torch.float64, device="cuda")
+
+        def local(R, t):
+            ds.accumulate6_async(R, t, LOSS, out)
+            return out
+
+        asm = distributed.ShardedAssembler(local)
+        pose = solvers.Pose()
+
+        def iterate(k):
+            nonlocal pose_t, pose_R
+            r = distributed.solve_ndt6(asm, solvers.Options(k, 0.0, 0.0), pose)
+            if r.iterations != k:
+                raise RuntimeError("LM loop ended after %d of %d iterations" % (r.iterations, k))
+            rep[:4] = [r.iterations, r.printed_cost, r.last_cost, r.final_lambda]
+            pose_t, pose_R = pose.t, pose.R.reshape(-1)
+
+    def fence():
+        torch.cuda.synchronize()
+        ctx.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    if args.warmup > 0:
+        iterate(args.warmup)
+    fence()
+    ctx.profile_begin(args.steps + 8)
+    t0 = time.perf_counter()
+    iterate(args.steps)
+    fence()
+    elapsed = time.perf_counter() - t0
+    n_timed, k_mean_ms, k_min_ms, k_max_ms = ctx.profile_end()
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    n_total = n_local * world
+    value = n_total * args.steps / elapsed
+    bytes_per_launch = n_local * BYTES_PER_CORR[args.dtype]
+    achieved = bytes_per_launch / (k_mean_ms * 1e-3) / 1e9 if k_mean_ms > 0 else 0.0
+    Rt, tt_true = synth.true_pose("ndt")
+    pose_err = float(np.max(np.abs(np.asarray(pose_t) - tt_true)))
+
+    result = {
+        "metric": "ndt6_gauss_newton_residual_blocks_per_sec",
+        "value": value,
+        "unit": "corr/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": args.dtype,
+        "data": "synthetic",
+        "config": {
+            "workload": "mahalanobis_distance_minimizer 6-DoF %s, %d points / %d NDT voxels per GPU "
+                        "(BASELINE.json configs[1]; x%d GPUs = configs[3] shape)" % (args.dtype, n_local, N_VOXELS, world),
+            "points_per_gpu": n_local, "total_points": n_total, "voxels": N_VOXELS,
+            "loss": "ExponentialLossFunction(1,1)", "parallelism": "corr-shard x%d, all-reduce 28 f64" % world,
+            "step": "LM iteration: assemble kernel + final reduce%s + 224 B readback + host 6x6 LDLT/pose update"
+                    % (" + RCCL all-reduce(28 f64)" if world > 1 else ""),
+        },
+        "scalar_residuals_per_sec": 3.0 * value,
+        "gn_iters_per_sec": args.steps / elapsed,
+        "final_translation_error_m": pose_err,
+        "lm_last_cost": float(rep[2]),
+        "roofline": {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+            "kernel": "nos::assemble_kernel<Ndt6Problem<%s, exponential>>" % ("double" if args.dtype == "f64" else "float"),
+            "kernel_ms_mean": k_mean_ms, "kernel_ms_min": k_min_ms, "kernel_ms_max": k_max_ms,
+            "launches_timed": n_timed, "algorithmic_bytes_per_launch": bytes_per_launch,
+            "bytes_per_corr": BYTES_PER_CORR[args.dtype],
+            "frac_of_measured_copy_6290": achieved / HBM_MEASURED_COPY_GBPS,
+            "timing": "hipEvent pairs on the launch stream around every assemble launch of the timed steps",
+        },
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        avx, scalar = cpu_baseline(planes, args.cpu_seconds)
+        result["cpu_baseline"] = avx
+        result["cpu_baseline_scalar_fp64"] = scalar
+        result["gpu_over_cpu_avx"] = value / avx["value"]
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -30,7 +30,7 @@ C_ABI_SYMBOLS = (
     "nos_dataset_destroy", "nos_dataset_size", "nos_dataset_dtype", "nos_dataset_stream_bytes",
     "nos_ndt6_accumulate", "nos_ndt3_accumulate", "nos_reproj_accumulate",
     "nos_ndt6_accumulate_async", "nos_ndt3_accumulate_async", "nos_reproj_accumulate_async",
-    "nos_ctx_set_launch", "nos_ndt6_time_kernel", "nos_reproj_time_kernel",
+    "nos_ctx_set_launch", "nos_ctx_profile_begin", "nos_ctx_profile_end", "nos_ndt6_time_kernel", "nos_reproj_time_kernel",
     "nos_ndt3_time_kernel", "nos_status_string", "nos_last_error", "nos_version",
 )
 
@@ -75,6 +75,8 @@ def _declare(lib):
     lib.nos_ctx_set_stream.argtypes = [vp, i, vp]
     lib.nos_ctx_synchronize.argtypes = [vp]
     lib.nos_ctx_set_launch.argtypes = [vp, i, i]
+    lib.nos_ctx_profile_begin.argtypes = [vp, i]
+    lib.nos_ctx_profile_end.argtypes = [vp, ctypes.POINTER(i), dp, dp, dp]
     lib.nos_ndt_dataset_create.argtypes = [vp, sz, ctypes.POINTER(dp), i, c_void_pp]
     lib.nos_reproj_dataset_create.argtypes = [vp, sz, ctypes.POINTER(dp), i, c_void_pp]
     lib.nos_ndt_dataset_create_from_device.argtypes = [vp, sz, c_void_pp, i, i, c_void_pp]

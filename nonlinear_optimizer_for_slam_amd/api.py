@@ -66,6 +66,19 @@ class Context:
     def set_launch(self, blocks_per_cu=0, variant=0):
         check(self._lib.nos_ctx_set_launch(self._h, blocks_per_cu, variant), "nos_ctx_set_launch")
 
+    def profile_begin(self, max_launches=4096):
+        check(self._lib.nos_ctx_profile_begin(self._h, max_launches), "nos_ctx_profile_begin")
+
+    def profile_end(self):
+        """→ (n_launches, mean_ms, min_ms, max_ms) of the assemble kernels launched since profile_begin."""
+        n = ctypes.c_int()
+        mean = ctypes.c_double()
+        lo = ctypes.c_double()
+        hi = ctypes.c_double()
+        check(self._lib.nos_ctx_profile_end(self._h, ctypes.byref(n), ctypes.byref(mean), ctypes.byref(lo),
+                                            ctypes.byref(hi)), "nos_ctx_profile_end")
+        return n.value, mean.value, lo.value, hi.value
+
     def synchronize(self):
         check(self._lib.nos_ctx_synchronize(self._h), "nos_ctx_synchronize")
 

@@ -328,6 +328,74 @@ __device__ __forceinline__ void block_reduce_store(const double (&acc)[NOUT], do
   }
 }
 
+// ---------------------------------------------------------------- in-launch final reduce
+
+// When `counter` is set the grid finishes its own reduction: every block publishes its row,
+// takes a ticket, and the block that draws the last ticket sums all rows in fixed order and
+// writes the result (device pointer and/or host-mapped pinned pointer), then bumps a host
+// visible sequence word.  This removes the dependent 1-block kernel and the D2H memcpy from
+// the per-iteration critical path.  Hand-off protocol = /opt/skills/guides
+// cdna_hip_programming.md Guideline 16: storing wave drains (vmcnt(0)) → one lane
+// agent-scope release → asm vmcnt(0) → relaxed agent atomic ticket;  last block: ticket
+// value is the "poll", one lane agent-scope acquire → vmcnt(0) → barrier → plain loads.
+struct FusedFinal {
+  unsigned int* counter;           // device word, 0 before the launch; reset to 0 by the last block
+  double* out_dev;                 // device result (may be null)
+  double* out_host;                // host-mapped pinned result (may be null)
+  unsigned long long* seq_host;    // host-mapped pinned sequence word (may be null)
+  unsigned long long seq;          // value stored to *seq_host when the result is complete
+};
+
+template <int NOUT, int BLOCK>
+__device__ __forceinline__ void finish_in_last_block(const double* partials, const FusedFinal& fin) {
+  __shared__ unsigned int s_last;
+  constexpr int kCols = 32;
+  constexpr int kSlices = BLOCK / kCols;
+  __shared__ double red[kSlices][kCols];
+  // the row was stored by lanes 0..NOUT-1 of wave 0; thread 0 is in that wave
+  if (threadIdx.x < kWave) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned int ticket = __hip_atomic_fetch_add(fin.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned int last = (ticket == gridDim.x - 1) ? 1u : 0u;
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    s_last = last;
+  }
+  __syncthreads();
+  if (s_last == 0u) return;  // block-uniform
+  const int col = threadIdx.x % kCols;
+  const int slice = threadIdx.x / kCols;
+  double s = 0.0;
+  if (col < NOUT)
+    for (uint32_t r = slice; r < gridDim.x; r += kSlices) s += partials[size_t(r) * NOUT + col];
+  red[slice][col] = s;
+  __syncthreads();
+  if (threadIdx.x < NOUT) {
+    double tot = 0.0;
+#pragma unroll
+    for (int sl = 0; sl < kSlices; ++sl) tot += red[sl][threadIdx.x];
+    if (fin.out_dev != nullptr) fin.out_dev[threadIdx.x] = tot;
+    if (fin.out_host != nullptr)
+      __hip_atomic_store(fin.out_host + threadIdx.x, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (threadIdx.x < kWave) {
+    // results leave through lanes 0..NOUT-1 of wave 0: drain them, then one lane publishes
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0) {
+      __hip_atomic_store(fin.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+      if (fin.seq_host != nullptr) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: results before the sequence word
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(fin.seq_host, fin.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------- the assemble kernel
 
 // Grid-stride over chunks of BLOCK*ITEMS correspondences.  `n_chunks * BLOCK * ITEMS`
@@ -337,7 +405,8 @@ template <typename Problem, typename T, int ITEMS, int BLOCK, int MINW, bool NT>
 __global__ __launch_bounds__(BLOCK, MINW) void assemble_kernel(TiledLayout L,
                                                               typename Problem::Params P,
                                                               uint32_t n_chunks,
-                                                              double* __restrict__ partials) {
+                                                              double* __restrict__ partials,
+                                                              FusedFinal fin) {
   constexpr int kF = Problem::kFields;
   constexpr int kOut = Problem::kOut;
   constexpr uint32_t kChunk = BLOCK * ITEMS;
@@ -366,6 +435,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void assemble_kernel(TiledLayout L,
 #pragma unroll
   for (int k = 0; k < kOut; ++k) dacc[k] = double(acc[k]);
   block_reduce_store<kOut, BLOCK>(dacc, partials + size_t(blockIdx.x) * kOut);
+  if (fin.counter != nullptr) finish_in_last_block<kOut, BLOCK>(partials, fin);
 }
 
 // Fixed-order sum of the block rows: thread (slice, col) adds rows slice, slice+S, …;

@@ -231,3 +231,59 @@ int nos_host_damped_step3(const double out10[10], double lambda, double step[3])
 }
 
 }  // extern "C"
+
+// ---- fixed-iteration LM loops on an existing device dataset (bench / steady-state use): the
+// whole loop — kernel launch, 224-byte readback, damping, 6x6 LDLT, pose update, lambda
+// schedule — runs in C++ with no Python between iterations.  Tolerances are 0 so exactly
+// `iterations` GN/LM iterations execute. ----
+extern "C" {
+
+int nos_host_ndt6_iterate(nos_dataset* dataset, const nos_loss* loss, int iterations, double t[3], double R[9],
+                          double report[5]) {
+  nos_host::LmSettings s;
+  s.max_iterations = iterations;
+  s.gradient_tolerance = 0.0;
+  s.parameter_tolerance = 0.0;
+  int status = NOS_OK;
+  const nos_host::LmReport lm = nos_host::RunLm6(
+      s,
+      [&](const double* Rc, const double* tc, double* out) {
+        status = nos_ndt6_accumulate(dataset, Rc, tc, loss, out);
+        return status == NOS_OK;
+      },
+      t, R);
+  if (report != nullptr) {
+    report[0] = lm.iterations;
+    report[1] = lm.printed_cost;
+    report[2] = lm.last_cost;
+    report[3] = lm.final_lambda;
+    report[4] = status;
+  }
+  return lm.ok ? 1 : 0;
+}
+
+int nos_host_reproj_iterate(nos_dataset* dataset, const double intr[4], const nos_loss* loss, double min_depth,
+                            int iterations, double t[3], double R[9], double report[5]) {
+  nos_host::LmSettings s;
+  s.max_iterations = iterations;
+  s.gradient_tolerance = 0.0;
+  s.parameter_tolerance = 0.0;
+  int status = NOS_OK;
+  const nos_host::LmReport lm = nos_host::RunLm6(
+      s,
+      [&](const double* Rc, const double* tc, double* out) {
+        status = nos_reproj_accumulate(dataset, Rc, tc, intr, loss, min_depth, out);
+        return status == NOS_OK;
+      },
+      t, R);
+  if (report != nullptr) {
+    report[0] = lm.iterations;
+    report[1] = lm.printed_cost;
+    report[2] = lm.last_cost;
+    report[3] = lm.final_lambda;
+    report[4] = status;
+  }
+  return lm.ok ? 1 : 0;
+}
+
+}  // extern "C"

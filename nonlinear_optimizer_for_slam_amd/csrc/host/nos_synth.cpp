@@ -170,7 +170,18 @@ extern "C" {
 
 // planes: 15 caller-allocated arrays of n doubles (plane order of include/nos.h).
 // Returns 0 on success.  threads <= 0 → hardware concurrency.
+int nos_synth_ndt_shard(uint64_t seed, size_t n, size_t n_voxels, size_t first_block, double* const planes[15],
+                        int threads);
+
 int nos_synth_ndt(uint64_t seed, size_t n, size_t n_voxels, double* const planes[15], int threads) {
+  return nos_synth_ndt_shard(seed, n, n_voxels, 0, planes, threads);
+}
+
+// Same scene, but the point streams start at RNG block `first_block` (blocks of 65536 points):
+// rank r of a sharded run passes first_block = r * ceil(n / 65536) and gets points that are
+// disjoint from every other rank's while sharing the voxel map.
+int nos_synth_ndt_shard(uint64_t seed, size_t n, size_t n_voxels, size_t first_block, double* const planes[15],
+                        int threads) {
   if (!planes || n_voxels == 0) return 1;
   for (int k = 0; k < 15; ++k)
     if (!planes[k] && n > 0) return 1;
@@ -180,7 +191,7 @@ int nos_synth_ndt(uint64_t seed, size_t n, size_t n_voxels, double* const planes
   double Rt[9], tt[3];
   TruePoseNdt(Rt, tt);
   ParallelBlocks(n, threads, [&](size_t b, size_t begin, size_t end) {
-    Rng rng(StreamSeed(seed, 2, b));
+    Rng rng(StreamSeed(seed, 2, first_block + b));
     for (size_t i = begin; i < end; ++i) {
       const size_t v = size_t(rng.Uniform() * double(n_voxels)) % n_voxels;
       const Voxel& vx = voxels[v];

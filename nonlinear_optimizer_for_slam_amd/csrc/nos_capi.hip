@@ -52,8 +52,16 @@ struct DeviceSlot {
   hipStream_t stream = nullptr;    // own_stream or an external one
   double* partials = nullptr;      // [kMaxPartialRows][kMaxOut] device
   double* d_out = nullptr;         // [kMaxOut] device
-  double* h_out = nullptr;         // [kMaxOut] pinned host
+  double* h_out = nullptr;         // pinned, device-mapped host block: [0..27] result, [32] sequence word
+  double* h_out_dev = nullptr;     // device-side address of h_out
+  unsigned int* counter = nullptr; // device ticket word of the in-launch final reduce (kept at 0 between launches)
+  unsigned long long seq = 0;      // last sequence value handed to a fused launch
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+  // per-launch kernel timing (nos_ctx_profile_begin/_end): event pairs recorded on the
+  // launch stream around every assemble kernel while profiling is on
+  std::vector<hipEvent_t> prof_events;
+  size_t prof_used = 0;
+  bool prof_on = false;
 };
 
 }  // namespace
@@ -88,7 +96,7 @@ struct nos_dataset {
 
 namespace {
 
-constexpr size_t kDefaultTileLog2 = 12;  // 4096 correspondences per tile
+constexpr size_t kDefaultTileLog2 = 10;  // 1024 correspondences per tile
 
 size_t elem_size(int dtype) { return dtype == NOS_F32 ? sizeof(float) : sizeof(double); }
 
@@ -134,7 +142,7 @@ constexpr int kNumVariants = 5;
 
 template <typename Problem, typename T, int ITEMS, int BLOCK, int MINW>
 int launch_variant(const nos::TiledLayout& L, const typename Problem::Params& P, int grid_cap,
-                   bool nt, double* partials, hipStream_t stream, int* rows_out) {
+                   bool nt, double* partials, const nos::FusedFinal& fin, hipStream_t stream, int* rows_out) {
   constexpr uint32_t kChunk = BLOCK * ITEMS;
   if (L.n_padded % kChunk != 0) return fail(NOS_ERR_INVALID_ARGUMENT, "n_padded %% chunk != 0");
   if (L.tile_stride != 0 && ((size_t(L.tile_mask) + 1) % kChunk) != 0)
@@ -147,10 +155,10 @@ int launch_variant(const nos::TiledLayout& L, const typename Problem::Params& P,
   if (grid > kMaxPartialRows) grid = kMaxPartialRows;
   if (nt)
     hipLaunchKernelGGL((nos::assemble_kernel<Problem, T, ITEMS, BLOCK, MINW, true>), dim3(grid), dim3(BLOCK), 0,
-                       stream, L, P, n_chunks, partials);
+                       stream, L, P, n_chunks, partials, fin);
   else
     hipLaunchKernelGGL((nos::assemble_kernel<Problem, T, ITEMS, BLOCK, MINW, false>), dim3(grid), dim3(BLOCK), 0,
-                       stream, L, P, n_chunks, partials);
+                       stream, L, P, n_chunks, partials, fin);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(NOS_ERR_HIP, "assemble launch failed: %s", hipGetErrorString(e));
   *rows_out = grid;
@@ -159,30 +167,30 @@ int launch_variant(const nos::TiledLayout& L, const typename Problem::Params& P,
 
 template <typename Problem, typename T>
 int launch_by_variant(int variant, int blocks_per_cu, int num_cus, const nos::TiledLayout& L,
-                      const typename Problem::Params& P, bool nt, double* partials,
+                      const typename Problem::Params& P, bool nt, double* partials, const nos::FusedFinal& fin,
                       hipStream_t stream, int* rows_out) {
   if (variant < 0 || variant >= kNumVariants) variant = 0;
-#define NOS_CASE(idx, ITEMS_, BLOCK_, MINW_)                                                        \
+#define NOS_CASE(idx, ITEMS_, BLOCK_, MINW_, BPC_)                                                  \
   case idx: {                                                                                       \
-    const int bpc = blocks_per_cu > 0 ? blocks_per_cu : std::max(1, (MINW_ * 256) / BLOCK_);        \
-    return launch_variant<Problem, T, ITEMS_, BLOCK_, MINW_>(L, P, bpc * num_cus, nt, partials, stream, \
+    const int bpc = blocks_per_cu > 0 ? blocks_per_cu : BPC_;                                       \
+    return launch_variant<Problem, T, ITEMS_, BLOCK_, MINW_>(L, P, bpc * num_cus, nt, partials, fin, stream, \
                                                              rows_out);                             \
   }
   if constexpr (sizeof(T) == 8) {
     switch (variant) {
-      NOS_CASE(0, 2, 256, 2)
-      NOS_CASE(1, 1, 256, 3)
-      NOS_CASE(2, 1, 256, 2)
-      NOS_CASE(3, 2, 512, 2)
-      NOS_CASE(4, 1, 512, 3)
+      NOS_CASE(0, 1, 512, 3, 1)
+      NOS_CASE(1, 1, 256, 3, 2)
+      NOS_CASE(2, 1, 256, 2, 2)
+      NOS_CASE(3, 2, 256, 2, 2)
+      NOS_CASE(4, 2, 512, 2, 1)
     }
   } else {
     switch (variant) {
-      NOS_CASE(0, 4, 256, 2)
-      NOS_CASE(1, 2, 256, 4)
-      NOS_CASE(2, 4, 512, 2)
-      NOS_CASE(3, 1, 256, 4)
-      NOS_CASE(4, 2, 256, 5)
+      NOS_CASE(0, 2, 512, 4, 1)
+      NOS_CASE(1, 4, 256, 2, 2)
+      NOS_CASE(2, 1, 256, 4, 2)
+      NOS_CASE(3, 2, 256, 5, 2)
+      NOS_CASE(4, 2, 256, 4, 2)
     }
   }
 #undef NOS_CASE
@@ -192,17 +200,17 @@ int launch_by_variant(int variant, int blocks_per_cu, int num_cus, const nos::Ti
 template <template <typename, int> class ProblemT, typename T, typename ParamsT>
 int launch_by_loss(int loss_kind, int variant, int blocks_per_cu, int num_cus,
                    const nos::TiledLayout& L, const ParamsT& P, bool nt, double* partials,
-                   hipStream_t stream, int* rows_out) {
+                   const nos::FusedFinal& fin, hipStream_t stream, int* rows_out) {
   switch (loss_kind) {
     case NOS_LOSS_NONE:
       return launch_by_variant<ProblemT<T, nos::kLossNone>, T>(variant, blocks_per_cu, num_cus, L, P, nt, partials,
-                                                               stream, rows_out);
+                                                               fin, stream, rows_out);
     case NOS_LOSS_EXPONENTIAL:
       return launch_by_variant<ProblemT<T, nos::kLossExponential>, T>(variant, blocks_per_cu, num_cus, L, P, nt,
-                                                                      partials, stream, rows_out);
+                                                                      partials, fin, stream, rows_out);
     case NOS_LOSS_HUBER:
       return launch_by_variant<ProblemT<T, nos::kLossHuber>, T>(variant, blocks_per_cu, num_cus, L, P, nt, partials,
-                                                                stream, rows_out);
+                                                                fin, stream, rows_out);
   }
   return fail(NOS_ERR_INVALID_ARGUMENT, "unknown loss kind %d", loss_kind);
 }
@@ -254,8 +262,27 @@ bool use_nontemporal(const nos_dataset* ds, const Shard& sh) {
   return sh.bytes > (size_t(192) << 20);
 }
 
+int launch_assemble_raw(const nos_dataset* ds, const Shard& sh, const Request& rq, double* partials,
+                        const nos::FusedFinal& fin, hipStream_t stream, int* rows_out);
+
+// Launches the assemble kernel; with profiling on, brackets it with an event pair on the
+// same stream so its device duration can be read back later without perturbing the loop.
 int launch_assemble(const nos_dataset* ds, const Shard& sh, const Request& rq, double* partials,
-                    hipStream_t stream, int* rows_out) {
+                    const nos::FusedFinal& fin, hipStream_t stream, int* rows_out) {
+  DeviceSlot& slot = ds->ctx->slots[sh.slot];
+  const bool prof = slot.prof_on && slot.prof_used + 2 <= slot.prof_events.size();
+  if (prof) NOS_HIP_CHECK(hipEventRecord(slot.prof_events[slot.prof_used], stream));
+  const int rc = launch_assemble_raw(ds, sh, rq, partials, fin, stream, rows_out);
+  if (rc != NOS_OK) return rc;
+  if (prof) {
+    NOS_HIP_CHECK(hipEventRecord(slot.prof_events[slot.prof_used + 1], stream));
+    slot.prof_used += 2;
+  }
+  return NOS_OK;
+}
+
+int launch_assemble_raw(const nos_dataset* ds, const Shard& sh, const Request& rq, double* partials,
+                        const nos::FusedFinal& fin, hipStream_t stream, int* rows_out) {
   const nos_ctx* ctx = ds->ctx;
   const DeviceSlot& slot = ctx->slots[sh.slot];
   const bool nt = use_nontemporal(ds, sh);
@@ -268,14 +295,14 @@ int launch_assemble(const nos_dataset* ds, const Shard& sh, const Request& rq, d
       for (int k = 0; k < 3; ++k) P.t[k] = rq.t[k];
       fill_loss(&rq.loss, P.la, P.lb, P.lc);
       return launch_by_loss<nos::Ndt6Problem, double>(rq.loss_kind, variant, bpc, slot.num_cus, sh.layout, P, nt,
-                                                      partials, stream, rows_out);
+                                                      partials, fin, stream, rows_out);
     }
     nos::Ndt6Params<float> P;
     for (int k = 0; k < 9; ++k) P.R[k] = float(rq.R[k]);
     for (int k = 0; k < 3; ++k) P.t[k] = float(rq.t[k]);
     fill_loss(&rq.loss, P.la, P.lb, P.lc);
     return launch_by_loss<nos::Ndt6Problem, float>(rq.loss_kind, variant, bpc, slot.num_cus, sh.layout, P, nt,
-                                                   partials, stream, rows_out);
+                                                   partials, fin, stream, rows_out);
   }
   if (rq.problem == 3) {
     if (ds->dtype == NOS_F64) {
@@ -284,14 +311,14 @@ int launch_assemble(const nos_dataset* ds, const Shard& sh, const Request& rq, d
       for (int k = 0; k < 2; ++k) P.t2[k] = rq.t[k];
       fill_loss(&rq.loss, P.la, P.lb, P.lc);
       return launch_by_loss<nos::Ndt3Problem, double>(rq.loss_kind, variant, bpc, slot.num_cus, sh.layout, P, nt,
-                                                      partials, stream, rows_out);
+                                                      partials, fin, stream, rows_out);
     }
     nos::Ndt3Params<float> P;
     for (int k = 0; k < 4; ++k) P.R2[k] = float(rq.R[k]);
     for (int k = 0; k < 2; ++k) P.t2[k] = float(rq.t[k]);
     fill_loss(&rq.loss, P.la, P.lb, P.lc);
     return launch_by_loss<nos::Ndt3Problem, float>(rq.loss_kind, variant, bpc, slot.num_cus, sh.layout, P, nt,
-                                                   partials, stream, rows_out);
+                                                   partials, fin, stream, rows_out);
   }
   if (ds->dtype == NOS_F64) {
     nos::ReprojParams<double> P;
@@ -304,7 +331,7 @@ int launch_assemble(const nos_dataset* ds, const Shard& sh, const Request& rq, d
     P.min_depth = rq.min_depth;
     fill_loss(&rq.loss, P.la, P.lb, P.lc);
     return launch_by_loss<nos::ReprojProblem, double>(rq.loss_kind, variant, bpc, slot.num_cus, sh.layout, P, nt,
-                                                      partials, stream, rows_out);
+                                                      partials, fin, stream, rows_out);
   }
   nos::ReprojParams<float> P;
   for (int k = 0; k < 9; ++k) P.R[k] = float(rq.R[k]);
@@ -316,7 +343,7 @@ int launch_assemble(const nos_dataset* ds, const Shard& sh, const Request& rq, d
   P.min_depth = float(rq.min_depth);
   fill_loss(&rq.loss, P.la, P.lb, P.lc);
   return launch_by_loss<nos::ReprojProblem, float>(rq.loss_kind, variant, bpc, slot.num_cus, sh.layout, P, nt,
-                                                   partials, stream, rows_out);
+                                                   partials, fin, stream, rows_out);
 }
 
 int launch_final(int n_out, const double* partials, int rows, double* out, hipStream_t stream) {
@@ -353,25 +380,63 @@ int build_request(int problem, const nos_dataset* ds, const double* R, int nR, c
   return NOS_OK;
 }
 
+constexpr int kSeqSlot = 32;  // index (in doubles) of the sequence word inside the pinned block
+
+// Spin on the host-mapped sequence word the last block stores after the result; falls back
+// to a stream synchronise if the word has not arrived after a generous bound, so a protocol
+// error can never hang the caller.
+int wait_for_sequence(DeviceSlot& slot) {
+  volatile unsigned long long* seq = reinterpret_cast<volatile unsigned long long*>(slot.h_out + kSeqSlot);
+  const unsigned long long want = slot.seq;
+  for (long spins = 0; *seq != want; ++spins) {
+    if (spins > 2000000) {
+      NOS_HIP_CHECK(hipSetDevice(slot.device));
+      NOS_HIP_CHECK(hipStreamSynchronize(slot.stream));
+      if (*seq != want) return fail(NOS_ERR_HIP, "fused final reduce did not publish its sequence word");
+      break;
+    }
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  return NOS_OK;
+}
+
 // Blocking accumulate over every shard; shard sums are added on the host in shard order
 // (the reference sums its per-thread partials the same way).
 int accumulate_sync(nos_dataset* ds, const Request& rq, double* out) {
   nos_ctx* ctx = ds->ctx;
+  const bool fused = env_int("NOS_FUSED", 1) != 0;
   for (const Shard& sh : ds->shards) {
     DeviceSlot& slot = ctx->slots[sh.slot];
     NOS_HIP_CHECK(hipSetDevice(slot.device));
     int rows = 0;
-    int rc = launch_assemble(ds, sh, rq, slot.partials, slot.stream, &rows);
-    if (rc != NOS_OK) return rc;
-    rc = launch_final(rq.n_out, slot.partials, rows, slot.d_out, slot.stream);
-    if (rc != NOS_OK) return rc;
-    NOS_HIP_CHECK(hipMemcpyAsync(slot.h_out, slot.d_out, sizeof(double) * rq.n_out, hipMemcpyDeviceToHost, slot.stream));
+    if (fused) {
+      // one launch: the last block to finish reduces all rows and writes the result plus a
+      // sequence word straight into pinned host memory (no second kernel, no memcpy)
+      nos::FusedFinal fin{slot.counter, nullptr, slot.h_out_dev,
+                          reinterpret_cast<unsigned long long*>(slot.h_out_dev + kSeqSlot), ++slot.seq};
+      int rc = launch_assemble(ds, sh, rq, slot.partials, fin, slot.stream, &rows);
+      if (rc != NOS_OK) return rc;
+    } else {
+      int rc = launch_assemble(ds, sh, rq, slot.partials, nos::FusedFinal{}, slot.stream, &rows);
+      if (rc != NOS_OK) return rc;
+      rc = launch_final(rq.n_out, slot.partials, rows, slot.d_out, slot.stream);
+      if (rc != NOS_OK) return rc;
+      NOS_HIP_CHECK(hipMemcpyAsync(slot.h_out, slot.d_out, sizeof(double) * rq.n_out, hipMemcpyDeviceToHost, slot.stream));
+    }
   }
   for (int k = 0; k < rq.n_out; ++k) out[k] = 0.0;
   for (const Shard& sh : ds->shards) {
     DeviceSlot& slot = ctx->slots[sh.slot];
-    NOS_HIP_CHECK(hipSetDevice(slot.device));
-    NOS_HIP_CHECK(hipStreamSynchronize(slot.stream));
+    if (fused) {
+      int rc = wait_for_sequence(slot);
+      if (rc != NOS_OK) return rc;
+    } else {
+      NOS_HIP_CHECK(hipSetDevice(slot.device));
+      NOS_HIP_CHECK(hipStreamSynchronize(slot.stream));
+    }
     for (int k = 0; k < rq.n_out; ++k) out[k] += slot.h_out[k];
   }
   return NOS_OK;
@@ -385,7 +450,11 @@ int accumulate_async(nos_dataset* ds, const Request& rq, double* d_out) {
   DeviceSlot& slot = ctx->slots[sh.slot];
   NOS_HIP_CHECK(hipSetDevice(slot.device));
   int rows = 0;
-  int rc = launch_assemble(ds, sh, rq, slot.partials, slot.stream, &rows);
+  if (env_int("NOS_FUSED", 1) != 0) {
+    nos::FusedFinal fin{slot.counter, d_out, nullptr, nullptr, 0};
+    return launch_assemble(ds, sh, rq, slot.partials, fin, slot.stream, &rows);
+  }
+  int rc = launch_assemble(ds, sh, rq, slot.partials, nos::FusedFinal{}, slot.stream, &rows);
   if (rc != NOS_OK) return rc;
   return launch_final(rq.n_out, slot.partials, rows, d_out, slot.stream);
 }
@@ -398,21 +467,28 @@ int time_kernel(nos_dataset* ds, const Request& rq, int repeats, double* kernel_
   NOS_HIP_CHECK(hipSetDevice(slot.device));
   int rows = 0;
   // warm-up
+  const bool fused = env_int("NOS_FUSED", 1) != 0;
   for (int i = 0; i < 2; ++i) {
-    int rc = launch_assemble(ds, sh, rq, slot.partials, slot.stream, &rows);
+    int rc = launch_assemble(ds, sh, rq, slot.partials, nos::FusedFinal{}, slot.stream, &rows);
     if (rc != NOS_OK) return rc;
   }
   NOS_HIP_CHECK(hipEventRecord(slot.ev0, slot.stream));
   for (int i = 0; i < repeats; ++i) {
-    int rc = launch_assemble(ds, sh, rq, slot.partials, slot.stream, &rows);
+    int rc = launch_assemble(ds, sh, rq, slot.partials, nos::FusedFinal{}, slot.stream, &rows);
     if (rc != NOS_OK) return rc;
   }
   NOS_HIP_CHECK(hipEventRecord(slot.ev1, slot.stream));
   for (int i = 0; i < repeats; ++i) {
-    int rc = launch_assemble(ds, sh, rq, slot.partials, slot.stream, &rows);
-    if (rc != NOS_OK) return rc;
-    rc = launch_final(rq.n_out, slot.partials, rows, slot.d_out, slot.stream);
-    if (rc != NOS_OK) return rc;
+    if (fused) {
+      nos::FusedFinal fin{slot.counter, slot.d_out, nullptr, nullptr, 0};
+      int rc = launch_assemble(ds, sh, rq, slot.partials, fin, slot.stream, &rows);
+      if (rc != NOS_OK) return rc;
+    } else {
+      int rc = launch_assemble(ds, sh, rq, slot.partials, nos::FusedFinal{}, slot.stream, &rows);
+      if (rc != NOS_OK) return rc;
+      rc = launch_final(rq.n_out, slot.partials, rows, slot.d_out, slot.stream);
+      if (rc != NOS_OK) return rc;
+    }
   }
   NOS_HIP_CHECK(hipEventRecord(slot.ev2, slot.stream));
   NOS_HIP_CHECK(hipEventSynchronize(slot.ev2));
@@ -695,7 +771,11 @@ int nos_ctx_create(const int* device_ids, int n_devices, nos_ctx** out_ctx) {
     }
     if (e == hipSuccess) e = hipMalloc(&s.partials, sizeof(double) * kMaxPartialRows * kMaxOut);
     if (e == hipSuccess) e = hipMalloc(&s.d_out, sizeof(double) * kMaxOut);
-    if (e == hipSuccess) e = hipHostMalloc(&s.h_out, sizeof(double) * kMaxOut, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc(&s.h_out, sizeof(double) * 64, hipHostMallocMapped);
+    if (e == hipSuccess) memset(s.h_out, 0, sizeof(double) * 64);
+    if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&s.h_out_dev), s.h_out, 0);
+    if (e == hipSuccess) e = hipMalloc(&s.counter, 64);
+    if (e == hipSuccess) e = hipMemset(s.counter, 0, 64);
     if (e == hipSuccess) e = hipEventCreate(&s.ev0);
     if (e == hipSuccess) e = hipEventCreate(&s.ev1);
     if (e == hipSuccess) e = hipEventCreate(&s.ev2);
@@ -721,9 +801,11 @@ int nos_ctx_destroy(nos_ctx* ctx) {
     if (s.partials) (void)hipFree(s.partials);
     if (s.d_out) (void)hipFree(s.d_out);
     if (s.h_out) (void)hipHostFree(s.h_out);
+    if (s.counter) (void)hipFree(s.counter);
     if (s.ev0) (void)hipEventDestroy(s.ev0);
     if (s.ev1) (void)hipEventDestroy(s.ev1);
     if (s.ev2) (void)hipEventDestroy(s.ev2);
+    for (hipEvent_t e : s.prof_events) (void)hipEventDestroy(e);
   }
   delete ctx;
   return NOS_OK;
@@ -879,6 +961,46 @@ int nos_reproj_time_kernel(nos_dataset* ds, const double R[9], const double t[3]
   int rc = build_request(2, ds, R, 9, t, 3, intr, min_depth, loss, &rq);
   if (rc != NOS_OK) return rc;
   return time_kernel(ds, rq, repeats, kernel_ms, total_ms);
+}
+
+int nos_ctx_profile_begin(nos_ctx* ctx, int max_launches) {
+  if (!ctx || max_launches < 1 || max_launches > (1 << 20)) return fail(NOS_ERR_INVALID_ARGUMENT, "bad profile request");
+  for (DeviceSlot& s : ctx->slots) {
+    NOS_HIP_CHECK(hipSetDevice(s.device));
+    while (s.prof_events.size() < size_t(max_launches) * 2) {
+      hipEvent_t e = nullptr;
+      NOS_HIP_CHECK(hipEventCreate(&e));
+      s.prof_events.push_back(e);
+    }
+    s.prof_used = 0;
+    s.prof_on = true;
+  }
+  return NOS_OK;
+}
+
+int nos_ctx_profile_end(nos_ctx* ctx, int* n_launches, double* mean_ms, double* min_ms, double* max_ms) {
+  if (!ctx) return fail(NOS_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  int count = 0;
+  double sum = 0.0, lo = 1e300, hi = 0.0;
+  for (DeviceSlot& s : ctx->slots) {
+    s.prof_on = false;
+    NOS_HIP_CHECK(hipSetDevice(s.device));
+    NOS_HIP_CHECK(hipStreamSynchronize(s.stream));
+    for (size_t i = 0; i + 1 < s.prof_used; i += 2) {
+      float ms = 0.f;
+      NOS_HIP_CHECK(hipEventElapsedTime(&ms, s.prof_events[i], s.prof_events[i + 1]));
+      sum += ms;
+      lo = std::min(lo, double(ms));
+      hi = std::max(hi, double(ms));
+      ++count;
+    }
+    s.prof_used = 0;
+  }
+  if (n_launches) *n_launches = count;
+  if (mean_ms) *mean_ms = count ? sum / count : 0.0;
+  if (min_ms) *min_ms = count ? lo : 0.0;
+  if (max_ms) *max_ms = count ? hi : 0.0;
+  return NOS_OK;
 }
 
 const char* nos_status_string(int status) {

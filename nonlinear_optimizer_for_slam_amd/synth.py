@@ -31,11 +31,14 @@ def _out_planes(count, n):
     return planes, arr
 
 
-def ndt_planes(n, n_voxels, seed=SEED, threads=0):
-    """[15, n] float64: point(3), mean(3), sqrt-information(9, row-major)."""
+def ndt_planes(n, n_voxels, seed=SEED, threads=0, first_block=0):
+    """[15, n] float64: point(3), mean(3), sqrt-information(9, row-major).
+
+    first_block shifts the point RNG streams (blocks of 65536 points) so that ranks of a sharded
+    run draw disjoint points over the same voxel map."""
     planes, arr = _out_planes(15, n)
-    rc = host_lib().nos_synth_ndt(ctypes.c_uint64(seed), ctypes.c_size_t(n), ctypes.c_size_t(n_voxels), arr,
-                                  ctypes.c_int(threads))
+    rc = host_lib().nos_synth_ndt_shard(ctypes.c_uint64(seed), ctypes.c_size_t(n), ctypes.c_size_t(n_voxels),
+                                        ctypes.c_size_t(first_block), arr, ctypes.c_int(threads))
     if rc != 0:
         raise RuntimeError("nos_synth_ndt failed: %d" % rc)
     return planes

@@ -31,7 +31,7 @@ for dtype in dtypes:
                 for bpc in (0, 1, 2, 3, 4, 6, 8):
                     ctx.set_launch(bpc, variant)
                     try:
-                        k, tot = ds.time_kernel6(R, t, loss, repeats=10)
+                        k, tot = ds.time_kernel6(R, t, loss, repeats=int(os.environ.get("TUNE_REPEATS", "10")))
                     except Exception as exc:  # noqa: BLE001
                         print("ERR", dtype, tile, nt, variant, bpc, exc, flush=True)
                         continue
