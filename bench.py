@@ -211,6 +211,20 @@ def main():
             "timing": "hipEvent pairs on the launch stream around every assemble launch of the timed steps",
         },
     }
+    # HBM traffic per launch comes from rocprofv3 PMC passes of this same command (they cannot be
+    # collected from inside the process); use the committed summary when it is for this workload.
+    try:
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_summary.json")), reverse=True):
+            prof = json.load(open(path))
+            if prof.get("points_per_gpu") == n_local and prof.get("dtype") == args.dtype:
+                result["roofline"]["traffic"] = prof["traffic_bytes_per_launch"]
+                result["roofline"]["traffic_source"] = (
+                    "%s: 2 x FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes (gfx950 x2 correction)"
+                    % os.path.relpath(path, ROOT))
+                break
+    except Exception:  # a missing / malformed summary only loses the optional field
+        pass
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         avx, scalar = cpu_baseline(planes, args.cpu_seconds)
         result["cpu_baseline"] = avx
