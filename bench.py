@@ -87,6 +87,21 @@ def cpu_baseline(planes, seconds):
     return avx, scalar
 
 
+class _StdoutToStderr:
+    """RCCL prints a version banner on stdout at communicator creation; keep stdout for the one
+    JSON line by pointing fd 1 at stderr while communicators are being set up."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -98,11 +113,19 @@ def main():
     from nonlinear_optimizer_for_slam_amd import Context, NdtDataset, _lib, distributed, solvers, synth
 
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("NOS_BENCH_FORCE_DIST", "0") == "1"  # exercise the N>1 code path on one GPU
+    if world > 1 or force_dist:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if force_dist and world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+        with _StdoutToStderr():
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+            probe = torch.ones(1, device="cuda")
+            dist.all_reduce(probe)  # creates torch's communicator (and its banner) now
+            torch.cuda.synchronize()
     else:
         torch.cuda.set_device(local_rank)
 
@@ -111,6 +134,32 @@ def main():
     planes = synth.ndt_planes(n_local, N_VOXELS, first_block=rank * blocks_per_rank)
     ctx = Context((local_rank,))
     ds = NdtDataset.from_planes(ctx, planes, args.dtype)
+
+    # Data-path collective for N > 1: a native RCCL all-reduce of the 28 doubles inside
+    # libnos_hip.so (the LM loop then runs entirely in C++, as at N = 1).  It is bootstrapped
+    # and self-tested through torch.distributed; if any rank cannot bring it up, every rank
+    # uses torch.distributed.all_reduce from a Python callback instead (NOS_BENCH_COMM=torch
+    # forces that).
+    comm_mode = "none"
+    if dist is not None:
+        comm_mode = "torch.distributed"
+        if os.environ.get("NOS_BENCH_COMM", "rccl") == "rccl":
+            ok = 1.0
+            try:
+                with _StdoutToStderr():
+                    ctx.comm_init_from_torch()
+                    got = ctx.comm_allreduce([rank + 1.0, 1.0])
+                if abs(got[0] - world * (world + 1) / 2.0) > 1e-12 or abs(got[1] - world) > 1e-12:
+                    raise RuntimeError("native RCCL self-test mismatch: %r" % (got,))
+            except Exception as exc:  # noqa: BLE001
+                print("[bench] native RCCL unavailable on rank %d: %s" % (rank, exc), file=sys.stderr)
+                ok = 0.0
+            flag = torch.tensor([ok], device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if float(flag.item()) > 0.5:
+                comm_mode = "rccl-native"
+            elif ctx.comm_size > 0:
+                raise RuntimeError("native RCCL came up on this rank but not on all ranks")
     if not (rank == 0 and world == 1 and not args.no_cpu_baseline):
         del planes
         planes = None
@@ -121,7 +170,7 @@ def main():
     pose_R = np.eye(3).reshape(-1).copy()
     rep = np.zeros(5)
 
-    if world == 1:
+    if comm_mode != "torch.distributed":
         def iterate(k):
             ok = host.nos_host_ndt6_iterate(ds._h, ctypes.byref(loss), ctypes.c_int(k),
                                             pose_t.ctypes.data_as(_lib.c_double_p),
@@ -193,6 +242,7 @@ def main():
                         "(BASELINE.json configs[1]; x%d GPUs = configs[3] shape)" % (args.dtype, n_local, N_VOXELS, world),
             "points_per_gpu": n_local, "total_points": n_total, "voxels": N_VOXELS,
             "loss": "ExponentialLossFunction(1,1)", "parallelism": "corr-shard x%d, all-reduce 28 f64" % world,
+            "collective": comm_mode,
             "step": "LM iteration: assemble kernel + final reduce%s + 224 B readback + host 6x6 LDLT/pose update"
                     % (" + RCCL all-reduce(28 f64)" if world > 1 else ""),
         },

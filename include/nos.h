@@ -98,6 +98,21 @@ int nos_ctx_set_stream(nos_ctx* ctx, int shard, void* hip_stream);
 /* Block until all work enqueued on the context's streams has finished. */
 int nos_ctx_synchronize(nos_ctx* ctx);
 
+/* ---- inter-process reduction (one process per GPU) ------------------------------
+ * The reference sums per-thread partials on the caller (MDM/..._analytic_simd.cc:70-75); with
+ * one process per GPU that sum is a single RCCL all-reduce of the 28 (10) doubles over xGMI.
+ * Rank 0 calls nos_comm_get_unique_id and hands the 128 bytes to every rank out of band
+ * (torch.distributed / MPI / a file); every rank then calls nos_ctx_comm_init (collective).
+ * From then on every *_accumulate / *_accumulate_async on that context returns the sum over
+ * all ranks (identical bits on every rank), so the unchanged host LM loop runs in lock-step.
+ * RCCL is loaded with dlopen on first use. */
+#define NOS_COMM_ID_BYTES 128
+int nos_comm_get_unique_id(unsigned char id[NOS_COMM_ID_BYTES]);
+int nos_ctx_comm_init(nos_ctx* ctx, int n_ranks, int rank, const unsigned char id[NOS_COMM_ID_BYTES]);
+int nos_ctx_comm_size(const nos_ctx* ctx); /* 0 if no communicator */
+/* Sum `count` (<= 28) host doubles over the ranks, in place (diagnostic / self-test). */
+int nos_ctx_comm_allreduce(nos_ctx* ctx, double* values, int count);
+
 /* ---- datasets ------------------------------------------------------------------
  * Replaces the per-Solve AoS→SoA pack (SOAData, MDM/..._analytic_simd.h:15-19 and
  * .cc:19-28; AlignedBufferVarious, MDM/..._analytic_simd_various.h:14-44; AlignedBuffer,

@@ -24,7 +24,8 @@ NOS_LOSS_HUBER = 2
 # every symbol include/nos.h declares; tests check the library exports all of them
 C_ABI_SYMBOLS = (
     "nos_ctx_create", "nos_ctx_destroy", "nos_ctx_num_devices", "nos_ctx_set_stream",
-    "nos_ctx_synchronize", "nos_ndt_dataset_create", "nos_reproj_dataset_create",
+    "nos_ctx_synchronize", "nos_comm_get_unique_id", "nos_ctx_comm_init", "nos_ctx_comm_size",
+    "nos_ctx_comm_allreduce", "nos_ndt_dataset_create", "nos_reproj_dataset_create",
     "nos_ndt_dataset_create_from_device", "nos_reproj_dataset_create_from_device",
     "nos_ndt_dataset_create_from_records", "nos_reproj_dataset_create_from_records",
     "nos_dataset_destroy", "nos_dataset_size", "nos_dataset_dtype", "nos_dataset_stream_bytes",
@@ -75,6 +76,10 @@ def _declare(lib):
     lib.nos_ctx_set_stream.argtypes = [vp, i, vp]
     lib.nos_ctx_synchronize.argtypes = [vp]
     lib.nos_ctx_set_launch.argtypes = [vp, i, i]
+    lib.nos_comm_get_unique_id.argtypes = [ctypes.c_char_p]
+    lib.nos_ctx_comm_init.argtypes = [vp, i, i, ctypes.c_char_p]
+    lib.nos_ctx_comm_size.argtypes = [vp]
+    lib.nos_ctx_comm_allreduce.argtypes = [vp, dp, i]
     lib.nos_ctx_profile_begin.argtypes = [vp, i]
     lib.nos_ctx_profile_end.argtypes = [vp, ctypes.POINTER(i), dp, dp, dp]
     lib.nos_ndt_dataset_create.argtypes = [vp, sz, ctypes.POINTER(dp), i, c_void_pp]

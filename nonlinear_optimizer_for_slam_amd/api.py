@@ -41,6 +41,13 @@ def _dp(a):
     return a.ctypes.data_as(c_double_p)
 
 
+def new_unique_id():
+    """128-byte RCCL unique id (rank 0 creates it, all ranks pass it to Context.comm_init)."""
+    buf = ctypes.create_string_buffer(128)
+    check(hip_lib().nos_comm_get_unique_id(buf), "nos_comm_get_unique_id")
+    return buf.raw
+
+
 class Context:
     """nos_ctx: one HIP stream + workspace per listed device (include/nos.h)."""
 
@@ -65,6 +72,29 @@ class Context:
 
     def set_launch(self, blocks_per_cu=0, variant=0):
         check(self._lib.nos_ctx_set_launch(self._h, blocks_per_cu, variant), "nos_ctx_set_launch")
+
+    def comm_init(self, n_ranks, rank, unique_id):
+        """Collective: join the RCCL communicator identified by the 128-byte unique_id."""
+        buf = ctypes.create_string_buffer(bytes(unique_id), 128)
+        check(self._lib.nos_ctx_comm_init(self._h, n_ranks, rank, buf), "nos_ctx_comm_init")
+
+    def comm_init_from_torch(self, group=None):
+        """Bootstrap the native RCCL communicator through an initialised torch.distributed group:
+        rank 0 creates the unique id, broadcasts it, every rank joins."""
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        payload = [new_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(payload, src=0, group=group)
+        self.comm_init(world, rank, payload[0])
+
+    @property
+    def comm_size(self):
+        return int(self._lib.nos_ctx_comm_size(self._h))
+
+    def comm_allreduce(self, values):
+        v = np.ascontiguousarray(values, dtype=np.float64).copy()
+        check(self._lib.nos_ctx_comm_allreduce(self._h, _dp(v), v.size), "nos_ctx_comm_allreduce")
+        return v
 
     def profile_begin(self, max_launches=4096):
         check(self._lib.nos_ctx_profile_begin(self._h, max_launches), "nos_ctx_profile_begin")

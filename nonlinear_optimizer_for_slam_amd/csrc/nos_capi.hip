@@ -4,6 +4,8 @@
 // the launch logic around the kernels in assemble_kernels.hpp.  There is no CPU fallback:
 // without a usable HIP device every entry point fails with NOS_ERR_NO_DEVICE / NOS_ERR_HIP.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <cmath>
@@ -40,6 +42,44 @@ int fail(int status, const char* fmt, ...) {
                   "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
   } while (0)
 
+// RCCL is bound at run time (dlopen) so that single-GPU use never needs it and so that a process
+// that already carries torch's copy of librccl shares that copy instead of loading a second one.
+struct RcclApi {
+  void* handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  bool ok = false;
+};
+
+RcclApi* Rccl() {
+  static RcclApi api;
+  static bool tried = false;
+  if (tried) return &api;
+  tried = true;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char* n : names) {
+    api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    if (api.handle) break;
+  }
+  if (!api.handle) return &api;
+  api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(api.handle, "ncclGetUniqueId"));
+  api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(api.handle, "ncclCommInitRank"));
+  api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.handle, "ncclCommDestroy"));
+  api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(api.handle, "ncclAllReduce"));
+  api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.handle, "ncclGetErrorString"));
+  api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllReduce && api.GetErrorString;
+  return &api;
+}
+
+#define NOS_RCCL_CHECK(expr)                                                                     \
+  do {                                                                                           \
+    ncclResult_t r_ = (expr);                                                                    \
+    if (r_ != ncclSuccess) return fail(NOS_ERR_HIP, "%s failed: %s", #expr, Rccl()->GetErrorString(r_)); \
+  } while (0)
+
 enum DatasetKind { kKindNdt = 1, kKindReproj = 2 };
 
 constexpr int kMaxPartialRows = 8192;  // upper bound on grid size of the assemble kernel
@@ -71,6 +111,8 @@ struct nos_ctx {
   int blocks_per_cu = 0;  // 0 = default
   int variant = 0;        // 0 = default; tuning knob (see pick_variant)
   int tile_log2 = -1;     // -1 = default; 0 = planar
+  ncclComm_t comm = nullptr;  // set by nos_ctx_comm_init: accumulate results are summed over its ranks
+  int comm_ranks = 1;
 };
 
 namespace {
@@ -382,6 +424,21 @@ int build_request(int problem, const nos_dataset* ds, const double* R, int nR, c
 
 constexpr int kSeqSlot = 32;  // index (in doubles) of the sequence word inside the pinned block
 
+// Device result → pinned host block + sequence word (used after an RCCL all-reduce, where the
+// in-launch final reduce cannot write to the host itself).
+__global__ void publish_kernel(const double* __restrict__ src, int n, double* dst_host,
+                               unsigned long long* seq_host, unsigned long long seq) {
+  if (int(threadIdx.x) < n)
+    __hip_atomic_store(dst_host + threadIdx.x, src[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(seq_host, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // Spin on the host-mapped sequence word the last block stores after the result; falls back
 // to a stream synchronise if the word has not arrived after a generous bound, so a protocol
 // error can never hang the caller.
@@ -408,6 +465,26 @@ int wait_for_sequence(DeviceSlot& slot) {
 int accumulate_sync(nos_dataset* ds, const Request& rq, double* out) {
   nos_ctx* ctx = ds->ctx;
   const bool fused = env_int("NOS_FUSED", 1) != 0;
+  if (ctx->comm != nullptr) {
+    // one process per GPU: local sums → RCCL all-reduce of the n_out doubles (in place, on the
+    // same stream) → publish to pinned host memory.  Every rank receives identical bits.
+    const Shard& sh = ds->shards[0];
+    DeviceSlot& slot = ctx->slots[sh.slot];
+    NOS_HIP_CHECK(hipSetDevice(slot.device));
+    int rows = 0;
+    nos::FusedFinal fin{slot.counter, slot.d_out, nullptr, nullptr, 0};
+    int rc = launch_assemble(ds, sh, rq, slot.partials, fin, slot.stream, &rows);
+    if (rc != NOS_OK) return rc;
+    NOS_RCCL_CHECK(Rccl()->AllReduce(slot.d_out, slot.d_out, size_t(rq.n_out), ncclDouble, ncclSum, ctx->comm,
+                                     slot.stream));
+    hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, slot.stream, slot.d_out, rq.n_out, slot.h_out_dev,
+                       reinterpret_cast<unsigned long long*>(slot.h_out_dev + kSeqSlot), ++slot.seq);
+    NOS_HIP_CHECK(hipGetLastError());
+    rc = wait_for_sequence(slot);
+    if (rc != NOS_OK) return rc;
+    for (int k = 0; k < rq.n_out; ++k) out[k] = slot.h_out[k];
+    return NOS_OK;
+  }
   for (const Shard& sh : ds->shards) {
     DeviceSlot& slot = ctx->slots[sh.slot];
     NOS_HIP_CHECK(hipSetDevice(slot.device));
@@ -450,6 +527,13 @@ int accumulate_async(nos_dataset* ds, const Request& rq, double* d_out) {
   DeviceSlot& slot = ctx->slots[sh.slot];
   NOS_HIP_CHECK(hipSetDevice(slot.device));
   int rows = 0;
+  if (ctx->comm != nullptr) {
+    nos::FusedFinal fin{slot.counter, d_out, nullptr, nullptr, 0};
+    int rc = launch_assemble(ds, sh, rq, slot.partials, fin, slot.stream, &rows);
+    if (rc != NOS_OK) return rc;
+    NOS_RCCL_CHECK(Rccl()->AllReduce(d_out, d_out, size_t(rq.n_out), ncclDouble, ncclSum, ctx->comm, slot.stream));
+    return NOS_OK;
+  }
   if (env_int("NOS_FUSED", 1) != 0) {
     nos::FusedFinal fin{slot.counter, d_out, nullptr, nullptr, 0};
     return launch_assemble(ds, sh, rq, slot.partials, fin, slot.stream, &rows);
@@ -792,6 +876,14 @@ int nos_ctx_create(const int* device_ids, int n_devices, nos_ctx** out_ctx) {
 
 int nos_ctx_destroy(nos_ctx* ctx) {
   if (!ctx) return NOS_OK;
+  if (ctx->comm != nullptr) {
+    if (!ctx->slots.empty()) {
+      (void)hipSetDevice(ctx->slots[0].device);
+      (void)hipStreamSynchronize(ctx->slots[0].stream);
+    }
+    (void)Rccl()->CommDestroy(ctx->comm);
+    ctx->comm = nullptr;
+  }
   for (DeviceSlot& s : ctx->slots) {
     (void)hipSetDevice(s.device);
     if (s.own_stream) {
@@ -961,6 +1053,47 @@ int nos_reproj_time_kernel(nos_dataset* ds, const double R[9], const double t[3]
   int rc = build_request(2, ds, R, 9, t, 3, intr, min_depth, loss, &rq);
   if (rc != NOS_OK) return rc;
   return time_kernel(ds, rq, repeats, kernel_ms, total_ms);
+}
+
+int nos_comm_get_unique_id(unsigned char id[NOS_COMM_ID_BYTES]) {
+  if (!id) return fail(NOS_ERR_INVALID_ARGUMENT, "id is NULL");
+  RcclApi* api = Rccl();
+  if (!api->ok) return fail(NOS_ERR_UNSUPPORTED, "librccl could not be loaded: %s", dlerror() ? dlerror() : "missing symbols");
+  static_assert(NOS_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "unique id size");
+  ncclUniqueId uid;
+  NOS_RCCL_CHECK(api->GetUniqueId(&uid));
+  memcpy(id, uid.internal, NOS_COMM_ID_BYTES);
+  return NOS_OK;
+}
+
+int nos_ctx_comm_init(nos_ctx* ctx, int n_ranks, int rank, const unsigned char id[NOS_COMM_ID_BYTES]) {
+  if (!ctx || !id || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(NOS_ERR_INVALID_ARGUMENT, "bad comm arguments");
+  if (ctx->slots.size() != 1) return fail(NOS_ERR_UNSUPPORTED, "a communicator needs a single-device context");
+  if (ctx->comm != nullptr) return fail(NOS_ERR_INVALID_ARGUMENT, "communicator already initialised");
+  RcclApi* api = Rccl();
+  if (!api->ok) return fail(NOS_ERR_UNSUPPORTED, "librccl could not be loaded");
+  NOS_HIP_CHECK(hipSetDevice(ctx->slots[0].device));
+  ncclUniqueId uid;
+  memcpy(uid.internal, id, NOS_COMM_ID_BYTES);
+  ncclComm_t comm = nullptr;
+  NOS_RCCL_CHECK(api->CommInitRank(&comm, n_ranks, uid, rank));
+  ctx->comm = comm;
+  ctx->comm_ranks = n_ranks;
+  return NOS_OK;
+}
+
+int nos_ctx_comm_size(const nos_ctx* ctx) { return (ctx && ctx->comm) ? ctx->comm_ranks : 0; }
+
+int nos_ctx_comm_allreduce(nos_ctx* ctx, double* values, int count) {
+  if (!ctx || !values || count < 1 || count > kMaxOut) return fail(NOS_ERR_INVALID_ARGUMENT, "bad allreduce arguments");
+  if (ctx->comm == nullptr) return fail(NOS_ERR_INVALID_ARGUMENT, "no communicator");
+  DeviceSlot& slot = ctx->slots[0];
+  NOS_HIP_CHECK(hipSetDevice(slot.device));
+  NOS_HIP_CHECK(hipMemcpyAsync(slot.d_out, values, sizeof(double) * count, hipMemcpyHostToDevice, slot.stream));
+  NOS_RCCL_CHECK(Rccl()->AllReduce(slot.d_out, slot.d_out, size_t(count), ncclDouble, ncclSum, ctx->comm, slot.stream));
+  NOS_HIP_CHECK(hipMemcpyAsync(values, slot.d_out, sizeof(double) * count, hipMemcpyDeviceToHost, slot.stream));
+  NOS_HIP_CHECK(hipStreamSynchronize(slot.stream));
+  return NOS_OK;
 }
 
 int nos_ctx_profile_begin(nos_ctx* ctx, int max_launches) {

@@ -285,3 +285,23 @@ def test_full_size_sample_against_oracle(ctx, oracle):
     want = oracle.ndt6_accumulate(planes, R_TEST, T_TEST, loss)
     helpers.assert_normal_equations_close(got, want, 6, RTOL_F64)
     ds.close()
+
+
+def test_native_rccl_single_rank_communicator(oracle):
+    """The in-library RCCL all-reduce path (one process per GPU) with a 1-rank communicator:
+    same sums as the plain path, self-test all-reduce is the identity."""
+    from nonlinear_optimizer_for_slam_amd.api import new_unique_id
+    planes = synth.ndt_planes(65_000, 3000)
+    loss = ("exponential", 1.0, 1.0)
+    c = Context((0,))
+    ds = NdtDataset.from_planes(c, planes, "f64")
+    want = ds.accumulate6(R_TEST, T_TEST, loss)
+    assert c.comm_size == 0
+    c.comm_init(1, 0, new_unique_id())
+    assert c.comm_size == 1
+    np.testing.assert_array_equal(c.comm_allreduce([3.0, 4.5]), [3.0, 4.5])
+    got = ds.accumulate6(R_TEST, T_TEST, loss)
+    assert np.array_equal(got, want)
+    helpers.assert_normal_equations_close(got, oracle.ndt6_accumulate(planes, R_TEST, T_TEST, loss), 6, RTOL_F64)
+    ds.close()
+    c.close()
