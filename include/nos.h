@@ -154,6 +154,35 @@ int nos_dataset_dtype(const nos_dataset* ds);
  * (n × planes × sizeof(element)); the figure roofline numbers are quoted against. */
 size_t nos_dataset_stream_bytes(const nos_dataset* ds);
 
+/* Copy a dataset back to host planes (n_fields arrays of nos_dataset_size doubles, plane order
+ * as above).  Diagnostics / tests only. */
+int nos_dataset_download(nos_dataset* ds, double* const planes[]);
+
+/* ---- correspondence matching on the device -----------------
+ * Replaces MatchPointCloud of the reference's test harness
+ * (MDM/tests/simple_optimization_test.cc:296-342): FLANN KDTreeSingleIndex over the valid
+ * voxel means + radiusSearch(radius = 1.0 on L2_Simple, i.e. squared distance, max_neighbors
+ * = 2) becomes a uniform-grid lookup on the GPU.  nos_ndt_match writes {local point, mean,
+ * sqrt-information} for the (up to) two nearest voxels of every scan point straight into a
+ * device dataset: slot 2*i + k holds the k-th nearest voxel of point i, an absent neighbour is
+ * an all-zero record (contributes nothing).  The dataset is then used with nos_ndt6_accumulate /
+ * nos_ndt3_accumulate like any other; nothing returns to the host between matching and solving.
+ * means_xyz: [n_voxels][3], sqrt_infos: [n_voxels][9] row-major, valid: optional [n_voxels]
+ * (NDT::is_valid, MDM/types.h:21; NULL = all valid), points_xyz: [n_points][3] in the scan's
+ * local frame.  Single-device contexts only. */
+typedef struct nos_ndt_map nos_ndt_map;
+typedef struct nos_scan nos_scan;
+int nos_ndt_map_create(nos_ctx* ctx, size_t n_voxels, const double* means_xyz,
+                       const double* sqrt_infos, const unsigned char* valid,
+                       double search_radius_sq, nos_ndt_map** out_map);
+int nos_ndt_map_destroy(nos_ndt_map* map);
+size_t nos_ndt_map_size(const nos_ndt_map* map); /* valid voxels */
+int nos_scan_create(nos_ctx* ctx, size_t n_points, const double* points_xyz, nos_scan** out_scan);
+int nos_scan_destroy(nos_scan* scan);
+size_t nos_scan_size(const nos_scan* scan);
+int nos_ndt_match(nos_ndt_map* map, nos_scan* scan, const double R[9], const double t[3],
+                  int max_neighbors, int dtype, nos_dataset** out_ds, size_t* n_matches);
+
 /* ---- the hot path -------------------------------------------------------------
  * nos_ndt6_accumulate replaces
  *   MahalanobisDistanceMinimizerAnalyticSIMD::ComputeCostAndDerivatives

@@ -28,7 +28,8 @@ C_ABI_SYMBOLS = (
     "nos_ctx_comm_allreduce", "nos_ndt_dataset_create", "nos_reproj_dataset_create",
     "nos_ndt_dataset_create_from_device", "nos_reproj_dataset_create_from_device",
     "nos_ndt_dataset_create_from_records", "nos_reproj_dataset_create_from_records",
-    "nos_dataset_destroy", "nos_dataset_size", "nos_dataset_dtype", "nos_dataset_stream_bytes",
+    "nos_dataset_download", "nos_ndt_map_create", "nos_ndt_map_destroy", "nos_ndt_map_size", "nos_scan_create",
+    "nos_scan_destroy", "nos_scan_size", "nos_ndt_match", "nos_dataset_destroy", "nos_dataset_size", "nos_dataset_dtype", "nos_dataset_stream_bytes",
     "nos_ndt6_accumulate", "nos_ndt3_accumulate", "nos_reproj_accumulate",
     "nos_ndt6_accumulate_async", "nos_ndt3_accumulate_async", "nos_reproj_accumulate_async",
     "nos_ctx_set_launch", "nos_ctx_profile_begin", "nos_ctx_profile_end", "nos_ndt6_time_kernel", "nos_reproj_time_kernel",
@@ -88,6 +89,16 @@ def _declare(lib):
     lib.nos_reproj_dataset_create_from_device.argtypes = [vp, sz, c_void_pp, i, i, c_void_pp]
     lib.nos_ndt_dataset_create_from_records.argtypes = [vp, sz, vp, sz, ctypes.POINTER(sz), i, c_void_pp]
     lib.nos_reproj_dataset_create_from_records.argtypes = [vp, sz, vp, sz, ctypes.POINTER(sz), i, c_void_pp]
+    lib.nos_dataset_download.argtypes = [vp, ctypes.POINTER(dp)]
+    lib.nos_ndt_map_create.argtypes = [vp, sz, dp, dp, ctypes.c_char_p, ctypes.c_double, c_void_pp]
+    lib.nos_ndt_map_destroy.argtypes = [vp]
+    lib.nos_ndt_map_size.argtypes = [vp]
+    lib.nos_ndt_map_size.restype = sz
+    lib.nos_scan_create.argtypes = [vp, sz, dp, c_void_pp]
+    lib.nos_scan_destroy.argtypes = [vp]
+    lib.nos_scan_size.argtypes = [vp]
+    lib.nos_scan_size.restype = sz
+    lib.nos_ndt_match.argtypes = [vp, vp, dp, dp, i, i, c_void_pp, ctypes.POINTER(sz)]
     lib.nos_dataset_destroy.argtypes = [vp]
     lib.nos_dataset_size.argtypes = [vp]
     lib.nos_dataset_size.restype = sz

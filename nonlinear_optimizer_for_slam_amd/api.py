@@ -299,3 +299,83 @@ class ReprojDataset(_Dataset):
                                                ctypes.c_double(min_depth), repeats, ctypes.byref(k),
                                                ctypes.byref(tot)), "nos_reproj_time_kernel")
         return k.value, tot.value
+
+
+class NdtMap:
+    """Device-resident NDT voxel map for matching (nos_ndt_map): means [V,3], sqrt-information
+    [V,3,3] row-major, optional validity mask; search_radius_sq is the FLANN `radius` of the
+    reference's MatchPointCloud (squared distance, 1.0 there)."""
+
+    def __init__(self, ctx, means, sqrt_infos, valid=None, search_radius_sq=1.0):
+        self._ctx = ctx
+        self._lib = ctx._lib
+        means = np.ascontiguousarray(means, dtype=np.float64).reshape(-1, 3)
+        S = np.ascontiguousarray(sqrt_infos, dtype=np.float64).reshape(-1, 9)
+        if means.shape[0] != S.shape[0]:
+            raise ValueError("means and sqrt_infos disagree on the voxel count")
+        vbuf = None
+        if valid is not None:
+            vbuf = np.ascontiguousarray(valid, dtype=np.uint8).tobytes()
+        h = ctypes.c_void_p()
+        check(self._lib.nos_ndt_map_create(ctx.handle, means.shape[0], _dp(means), _dp(S), vbuf,
+                                           ctypes.c_double(search_radius_sq), ctypes.byref(h)), "nos_ndt_map_create")
+        self._h = h
+
+    def __len__(self):
+        return int(self._lib.nos_ndt_map_size(self._h))
+
+    def match(self, scan, R, t, max_neighbors=2, dtype="f64"):
+        """→ (NdtDataset with 2 slots per scan point, number of real matches)."""
+        R = _dvec(R, 9)
+        t = _dvec(t, 3)
+        h = ctypes.c_void_p()
+        n = ctypes.c_size_t()
+        check(self._lib.nos_ndt_match(self._h, scan._h, _dp(R), _dp(t), max_neighbors, _DTYPES[dtype],
+                                      ctypes.byref(h), ctypes.byref(n)), "nos_ndt_match")
+        return NdtDataset(self._ctx, h), int(n.value)
+
+    def close(self):
+        if self._h:
+            self._lib.nos_ndt_map_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Scan:
+    """Device-resident scan points in the sensor's local frame (nos_scan): points [n,3]."""
+
+    def __init__(self, ctx, points):
+        self._ctx = ctx
+        self._lib = ctx._lib
+        pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+        h = ctypes.c_void_p()
+        check(self._lib.nos_scan_create(ctx.handle, pts.shape[0], _dp(pts), ctypes.byref(h)), "nos_scan_create")
+        self._h = h
+
+    def __len__(self):
+        return int(self._lib.nos_scan_size(self._h))
+
+    def close(self):
+        if self._h:
+            self._lib.nos_scan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def download(dataset):
+    """Dataset → host planes [n_planes, n] (diagnostics / tests)."""
+    n = len(dataset)
+    planes = np.zeros((dataset._n_planes, n))
+    arr = (c_double_p * dataset._n_planes)(*[planes[k].ctypes.data_as(c_double_p) for k in range(dataset._n_planes)])
+    check(dataset._lib.nos_dataset_download(dataset._h, arr), "nos_dataset_download")
+    return planes

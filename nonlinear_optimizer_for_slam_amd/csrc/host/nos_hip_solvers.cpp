@@ -177,6 +177,19 @@ bool MahalanobisDistanceMinimizerHip::SolvePrepared(const Options& options, Pose
   return RunLoop(options, prepared_, loss, pose);
 }
 
+bool MahalanobisDistanceMinimizerHip::SolveDataset(const Options& options, nos_dataset* dataset, Pose* pose) {
+  if (dataset == nullptr || pose == nullptr) return false;
+  nos_loss loss;
+  if (!DescribeLossFunction(loss_function_.get(), &loss)) {
+    std::cerr << "[nos-hip] unsupported LossFunction subclass: only Exponential and Huber have a device "
+                 "restatement and there is no CPU fallback"
+              << std::endl;
+    report_.status = NOS_ERR_UNSUPPORTED;
+    return false;
+  }
+  return RunLoop(options, dataset, loss, pose);
+}
+
 bool MahalanobisDistanceMinimizerHip::Solve(const Options& options,
                                             const std::vector<Correspondence>& correspondences, Pose* pose) {
   if (!Prepare(correspondences)) return false;

@@ -78,6 +78,9 @@ class MahalanobisDistanceMinimizerHip : public MahalanobisDistanceMinimizer {
   bool Prepare(const std::vector<Correspondence>& correspondences);
   bool SolvePrepared(const Options& options, Pose* pose);
   void ReleasePrepared();
+  // Additive API for GPU-resident pipelines: solve on a dataset that already lives on the device
+  // (e.g. the output of nos_ndt_match); the dataset stays owned by the caller.
+  bool SolveDataset(const Options& options, nos_dataset* dataset, Pose* pose);
 
   const HipSolveReport& report() const { return report_; }
 

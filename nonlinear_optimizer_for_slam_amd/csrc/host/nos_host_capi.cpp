@@ -287,3 +287,29 @@ int nos_host_reproj_iterate(nos_dataset* dataset, const double intr[4], const no
 }
 
 }  // extern "C"
+
+// Solve() of the drop-in classes on a dataset that already lives on the device (matcher output).
+extern "C" int nos_host_ndt_solve_dataset(int dof, nos_dataset* dataset, int loss_kind, double loss_a, double loss_b,
+                                          int max_iterations, double gradient_tolerance, double parameter_tolerance,
+                                          int print_cost_line, double t[3], double R[9], double report[5]) {
+  namespace mdm = nonlinear_optimizer::mahalanobis_distance_minimizer;
+  try {
+    HipOptions hip;
+    hip.print_cost_line = print_cost_line != 0;
+    std::unique_ptr<mdm::MahalanobisDistanceMinimizerHip> solver;
+    if (dof == 3)
+      solver = std::make_unique<mdm::MahalanobisDistanceMinimizerHip3DOF>(hip);
+    else
+      solver = std::make_unique<mdm::MahalanobisDistanceMinimizerHip>(hip);
+    solver->SetLossFunction(MakeLoss(loss_kind, loss_a, loss_b));
+    const Options options = MakeOptions(max_iterations, gradient_tolerance, parameter_tolerance);
+    Pose pose = Pose::Identity();
+    LoadPose(t, R, &pose);
+    const bool ok = solver->SolveDataset(options, dataset, &pose);
+    StoreReport(solver->report(), report);
+    if (ok) StorePose(pose, t, R);
+    return ok ? 1 : 0;
+  } catch (...) {
+    return 0;
+  }
+}

@@ -92,6 +92,24 @@ class MahalanobisDistanceMinimizerHip(_HipSolverBase):
         return bool(ok)
 
 
+    def SolveDataset(self, options, dataset, pose):
+        """Solve on a device-resident NdtDataset (e.g. the matcher's output); additive API."""
+        l = make_loss(self._loss)
+        t = np.ascontiguousarray(pose.t, dtype=np.float64).copy()
+        R = np.ascontiguousarray(pose.R, dtype=np.float64).reshape(-1).copy()
+        rep = np.zeros(5)
+        ok = host_lib().nos_host_ndt_solve_dataset(
+            ctypes.c_int(self._dof), dataset._h, ctypes.c_int(l.kind), ctypes.c_double(l.a), ctypes.c_double(l.b),
+            ctypes.c_int(options.max_iterations), ctypes.c_double(options.gradient_tolerance),
+            ctypes.c_double(options.parameter_tolerance), ctypes.c_int(int(self.print_cost_line)),
+            t.ctypes.data_as(_lib.c_double_p), R.ctypes.data_as(_lib.c_double_p), rep.ctypes.data_as(_lib.c_double_p))
+        self.report = SolveReport(rep)
+        if ok:
+            pose.t = t
+            pose.R = R.reshape(3, 3)
+        return bool(ok)
+
+
 class MahalanobisDistanceMinimizerHip3DOF(MahalanobisDistanceMinimizerHip):
     """Planar (x, y, yaw) NDT pose (↔ MahalanobisDistanceMinimizerAnalytic3DOF[SIMD])."""
     _dof = 3

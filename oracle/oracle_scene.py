@@ -1,0 +1,142 @@
+"""CPU restatement of the reference's NDT test harness — TEST INFRASTRUCTURE.
+
+Follows nonlinear_optimizer/mahalanobis_distance_minimizer/tests/simple_optimization_test.cc:
+  GenerateGlobalPoints :170-204   room 7 x 5 x 2.5 m, 1 cm grid, floor + 4 walls (loop variables
+                                  accumulated in floating point exactly as there)
+  FilterPoints         :206-222   first point per voxel key
+  ComputeVoxelKey      :283-294   Cantor pairing of folded integer voxel coordinates
+  UpdateNdtMap         :236-281   count / sum / moment (moment starts at IDENTITY, MDM/types.h:14),
+                                  mean, covariance, eigen-decomposition, eigenvalue flooring,
+                                  sqrt_information = diag(eigvals^-1/2) * eigenvectors
+  MatchPointCloud      :296-342   2 nearest valid voxel means within squared distance 1.0
+Known-answer values of the reference's captured runs (results/maha_amd64.txt:1-2): 954605 global
+points, 96 voxels; 9356 points after the 0.1 m filter.
+
+Eigen's SelfAdjointEigenSolver is replaced by numpy.linalg.eigh (same ascending eigenvalue order;
+eigenvector signs may differ, which changes S = D^-1/2 V for voxels with off-diagonal covariance:
+end-to-end NDT numbers are therefore a sanity band, not bit goldens — DESIGN.md §5).
+"""
+import numpy as np
+
+
+def generate_global_points():
+    width, length, height, step = 5.0, 7.0, 2.5, 0.01
+
+    def frange(a, b):
+        out = []
+        v = a
+        while v <= b:
+            out.append(v)
+            v += step
+        return np.array(out)
+
+    xs = frange(-length / 2.0, length / 2.0)
+    ys = frange(-width / 2.0, width / 2.0)
+    zs = frange(0.0, height)
+    pts = []
+    # floor
+    X, Y = np.meshgrid(xs, ys, indexing="ij")
+    pts.append(np.stack([X.ravel(), Y.ravel(), np.zeros(X.size)], axis=1))
+    # left/right wall: for x, for z: (x, y, z), (x, -y, z)
+    y = -width / 2.0
+    X, Z = np.meshgrid(xs, zs, indexing="ij")
+    a = np.stack([X.ravel(), np.full(X.size, y), Z.ravel()], axis=1)
+    b = np.stack([X.ravel(), np.full(X.size, -y), Z.ravel()], axis=1)
+    pts.append(np.stack([a, b], axis=1).reshape(-1, 3))
+    # front/back wall: for y, for z: (-x, y, z), (x, y, z)
+    x = -length / 2.0
+    Y, Z = np.meshgrid(ys, zs, indexing="ij")
+    a = np.stack([np.full(Y.size, -x), Y.ravel(), Z.ravel()], axis=1)
+    b = np.stack([np.full(Y.size, x), Y.ravel(), Z.ravel()], axis=1)
+    pts.append(np.stack([a, b], axis=1).reshape(-1, 3))
+    return np.concatenate(pts, axis=0)
+
+
+def voxel_keys(points, inv_res):
+    k = np.floor(points * inv_res).astype(np.int64)
+    k = np.where(k >= 0, 2 * k, -2 * k - 1)
+    xk, yk, zk = k[:, 0], k[:, 1], k[:, 2]
+    # the reference evaluates (x+y)*(x+y+1)/2 + y in `int`; values stay far below 2^31 here
+    xy = (xk + yk) * (xk + yk + 1) // 2 + yk
+    return ((xy + zk) * (xy + zk + 1) // 2 + zk).astype(np.uint64)
+
+
+def filter_points(points, voxel_size):
+    keys = voxel_keys(points, 1.0 / voxel_size)
+    _, first = np.unique(keys, return_index=True)
+    return points[np.sort(first)]
+
+
+def build_ndt_map(points, voxel_resolution=1.0):
+    """→ dict(means [V,3], sqrt_infos [V,3,3], valid [V], keys [V]) in first-seen voxel order."""
+    keys = voxel_keys(points, 1.0 / voxel_resolution)
+    uniq, first, inv = np.unique(keys, return_index=True, return_inverse=True)
+    order = np.argsort(first)  # first-seen order
+    rank = np.empty_like(order)
+    rank[order] = np.arange(order.size)
+    vid = rank[inv]
+    V = uniq.size
+    count = np.bincount(vid, minlength=V)
+    s = np.zeros((V, 3))
+    np.add.at(s, vid, points)
+    moment = np.tile(np.eye(3), (V, 1, 1))  # NDT::moment starts at Identity (MDM/types.h:14)
+    np.add.at(moment, vid, points[:, :, None] * points[:, None, :])
+    means = np.zeros((V, 3))
+    S = np.tile(np.eye(3), (V, 1, 1))
+    valid = np.zeros(V, dtype=bool)
+    for v in range(V):
+        if count[v] < 5:
+            continue
+        mean = s[v] / count[v]
+        cov = moment[v] / count[v] - np.outer(mean, mean)
+        w, U = np.linalg.eigh(cov)
+        if w[2] < 0.01:
+            # the reference `return`s here (harness bug); not reproduced
+            continue
+        w = w.copy()
+        w[0] = max(w[0], w[2] * 0.01)
+        w[1] = max(w[1], w[2] * 0.01)
+        means[v] = mean
+        S[v] = np.diag(1.0 / np.sqrt(w)) @ U
+        valid[v] = True
+    return {"means": means, "sqrt_infos": S, "valid": valid, "keys": uniq[order], "count": count}
+
+
+def match_point_cloud(means, sqrt_infos, valid, local_points, R, t, radius_sq=1.0, max_neighbors=2):
+    """Brute-force restatement of MatchPointCloud.  → (planes [15, 2n] with zero records for absent
+    neighbours — the slot convention of nos_ndt_match —, number of matches, index array [n, 2] (-1 = none))."""
+    means = np.asarray(means, dtype=np.float64).reshape(-1, 3)
+    S = np.asarray(sqrt_infos, dtype=np.float64).reshape(-1, 9)
+    ok = np.ones(means.shape[0], dtype=bool) if valid is None else np.asarray(valid, dtype=bool)
+    ids = np.nonzero(ok)[0]
+    R = np.asarray(R, dtype=np.float64).reshape(3, 3)
+    t = np.asarray(t, dtype=np.float64).reshape(3)
+    P = np.asarray(local_points, dtype=np.float64).reshape(-1, 3)
+    n = P.shape[0]
+    # same operation order as the kernel: R[0]*x + R[1]*y + R[2]*z + t
+    q = np.stack([R[r, 0] * P[:, 0] + R[r, 1] * P[:, 1] + R[r, 2] * P[:, 2] + t[r] for r in range(3)], axis=1)
+    idx = -np.ones((n, 2), dtype=np.int64)
+    chunk = max(1, 4_000_000 // max(1, ids.size))
+    for b in range(0, n, chunk):
+        qq = q[b:b + chunk]
+        ex = qq[:, None, 0] - means[None, ids, 0]
+        ey = qq[:, None, 1] - means[None, ids, 1]
+        ez = qq[:, None, 2] - means[None, ids, 2]
+        d = ex * ex + ey * ey + ez * ez
+        d = np.where(d < radius_sq, d, np.inf)
+        k = min(2, ids.size)
+        # stable sort → ties broken by original voxel id (ids ascending)
+        part = np.argsort(d, axis=1, kind="stable")[:, :k]
+        dsel = np.take_along_axis(d, part, axis=1)
+        sel = np.where(np.isfinite(dsel), ids[part], -1)
+        idx[b:b + chunk, :k] = sel
+    if max_neighbors < 2:
+        idx[:, 1] = -1
+    planes = np.zeros((15, 2 * n))
+    for k in range(2):
+        m = idx[:, k] >= 0
+        cols = 2 * np.nonzero(m)[0] + k
+        planes[0:3, cols] = P[m].T
+        planes[3:6, cols] = means[idx[m, k]].T
+        planes[6:15, cols] = S[idx[m, k]].T
+    return planes, int((idx >= 0).sum()), idx
