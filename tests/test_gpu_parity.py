@@ -106,12 +106,10 @@ def test_ingestion_paths_agree_bit_for_bit(ctx):
     rec = np.zeros((n, 38), dtype=np.float64)
     rec[:, 0:3] = planes[0:3].T
     rec[:, 16:19] = planes[3:6].T
-    offs = [0, 8, 16, 128, 136, 144]
     for i in range(3):
         for j in range(3):
             rec[:, 28 + 3 * j + i] = planes[6 + 3 * i + j]
-            offs.append(224 + 8 * (3 * j + i))
-    offs = offs[:6] + [224 + 8 * (3 * j + i) for i in range(3) for j in range(3)]
+    offs = [0, 8, 16, 128, 136, 144] + [224 + 8 * (3 * j + i) for i in range(3) for j in range(3)]
     c = NdtDataset.from_records(ctx, rec, 304, offs, "f64")
     assert len(c) == n
     assert np.array_equal(want, c.accumulate6(R_TEST, T_TEST, loss))
@@ -305,3 +303,55 @@ def test_native_rccl_single_rank_communicator(oracle):
     helpers.assert_normal_equations_close(got, oracle.ndt6_accumulate(planes, R_TEST, T_TEST, loss), 6, RTOL_F64)
     ds.close()
     c.close()
+
+
+@pytest.mark.parametrize("n", [3000, 400_000])
+def test_in_launch_final_reduce_never_reads_stale_rows(n):
+    """Hand-off stress for the fused final reduce (Guideline-16 protocol): alternate two poses so every
+    launch overwrites the block rows with different values; a stale row (missed release/acquire) would
+    reproduce the other pose's contribution.  Every launch must be bit-identical to the first launch of
+    its pose, for several launch geometries (1 … 8 blocks per CU)."""
+    planes = synth.ndt_planes(n, max(1, n // 40))
+    loss = ("exponential", 1.0, 1.0)
+    c = Context((0,))
+    ds = NdtDataset.from_planes(c, planes, "f64")
+    RA, tA = R_TEST, T_TEST
+    RB, tB = helpers.rot_xyz(-0.03, 0.02, -0.06), np.array([0.3, -0.2, -0.1])
+    for variant, bpc in ((0, 0), (1, 8), (3, 4)):
+        c.set_launch(bpc, variant)
+        a0 = ds.accumulate6(RA, tA, loss)
+        b0 = ds.accumulate6(RB, tB, loss)
+        assert not np.array_equal(a0, b0)
+        for _ in range(150):
+            assert np.array_equal(ds.accumulate6(RA, tA, loss), a0)
+            assert np.array_equal(ds.accumulate6(RB, tB, loss), b0)
+    ds.close()
+    c.close()
+
+
+def test_c_abi_argument_errors_are_reported_not_crashed(ctx):
+    import ctypes
+    from nonlinear_optimizer_for_slam_amd import _lib
+    lib = _lib.hip_lib()
+    planes = synth.ndt_planes(100, 5)
+    ds = NdtDataset.from_planes(ctx, planes, "f64")
+    rp = ReprojDataset.from_planes(ctx, synth.reproj_planes(100), "f64")
+    with pytest.raises(_lib.NosError) as e1:      # wrong dataset kind
+        rp_as_ndt = NdtDataset(ctx, rp._h)
+        try:
+            rp_as_ndt.accumulate6(np.eye(3), np.zeros(3))
+        finally:
+            rp_as_ndt._h = None
+    assert e1.value.status == 5
+    with pytest.raises(_lib.NosError) as e2:      # loss parameters validated like loss_function.h:24-25
+        ds.accumulate6(np.eye(3), np.zeros(3), ("exponential", -1.0, 1.0))
+    assert e2.value.status == 1
+    with pytest.raises(_lib.NosError):
+        ds.accumulate6(np.eye(3), np.zeros(3), ("huber", 0.0))
+    with pytest.raises(_lib.NosError):            # dtype
+        NdtDataset.from_planes(ctx, planes, 7) if False else _lib.check(
+            lib.nos_ndt_dataset_create(ctx.handle, 0, None, 7, ctypes.byref(ctypes.c_void_p())), "create")
+    assert lib.nos_ndt6_accumulate(None, None, None, None, None) == 1
+    assert b"NULL" in lib.nos_last_error()
+    ds.close()
+    rp.close()
