@@ -146,3 +146,31 @@ def test_gpu_scan_to_map_matches_oracle_loop_and_reference_band(ctx, oracle, roo
     assert np.max(np.abs(pose.t - np.array([-0.196416, 0.121469, 0.304836]))) < 5e-3
     sc.close()
     gm.close()
+
+
+@pytest.mark.gpu
+def test_cpp_demo_of_the_reference_ndt_test_runs_through_the_drop_in_classes():
+    """examples/ndt_scan_matching.cpp is the C++ caller's view: the reference's test scene, solved with
+    MahalanobisDistanceMinimizerHip::Solve on std::vector<Correspondence> (drop-in) and with the
+    GPU-resident matcher + SolveDataset; both must print the reference's known counts, agree with each
+    other and land in the reference's band."""
+    import os
+    import re
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "ndt_scan_matching")
+    assert os.path.exists(exe), "build with python __graft_entry__.py"
+    proc = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    err = proc.stderr
+    assert proc.returncode == 0, err
+    assert "# points: 954605" in err and "Ndt map size: 96" in err and "# scan points: 9356" in err
+    costs = re.findall(r"COST: ([0-9.e+]+), iter: (\d+)", err)
+    assert len(costs) >= 6
+    assert abs(float(costs[0][0]) - 17438.4) / 17438.4 < 0.015 and costs[0][1] == "40"
+
+    def pose(label):
+        m = re.search(re.escape(label) + r" (.*)", err)
+        return np.array([float(x) for x in m.group(1).split()])
+
+    a, b, t = pose("Pose (hip drop-in):"), pose("Pose (hip resident):"), pose("True pose:")
+    assert np.max(np.abs(a - b)) < 2e-6
+    assert np.max(np.abs(a[:3] - t[:3])) < 6e-3 and np.max(np.abs(a[3:] - t[3:])) < 2e-3
