@@ -65,7 +65,7 @@ std::vector<Vec3> FilterPoints(const std::vector<Vec3>& pts, double voxel) {
 }
 
 // Cyclic Jacobi for a symmetric 3x3; eigenvalues ascending, eigenvectors in the columns of V,
-// each column's largest-magnitude component made positive (a fixed, documented sign convention —
+// the first (near-)largest component of each column positive (a fixed, documented sign convention —
 // the reference takes whatever Eigen::SelfAdjointEigenSolver returns).
 void SymmetricEigen3(const double A[9], double w[3], double V[9]) {
   double a[9];
@@ -73,11 +73,14 @@ void SymmetricEigen3(const double A[9], double w[3], double V[9]) {
   for (int i = 0; i < 9; ++i) V[i] = (i % 4 == 0) ? 1.0 : 0.0;
   for (int sweep = 0; sweep < 60; ++sweep) {
     const double off = a[1] * a[1] + a[2] * a[2] + a[5] * a[5];
-    if (off < 1e-300) break;
+    const double diag = a[0] * a[0] + a[4] * a[4] + a[8] * a[8];
+    if (off <= 1e-26 * diag) break;
     for (int p = 0; p < 2; ++p)
       for (int q = p + 1; q < 3; ++q) {
         const double apq = a[3 * p + q];
-        if (std::fabs(apq) < 1e-300) continue;
+        // off-diagonals at rounding-noise level are treated as zero, so numerically diagonal matrices
+        // (axis-aligned patches) keep axis-aligned eigenvectors instead of a noise-driven rotation
+        if (std::fabs(apq) <= 1e-13 * (std::fabs(a[3 * p + p]) + std::fabs(a[3 * q + q]))) continue;
         const double theta = (a[3 * q + q] - a[3 * p + p]) / (2.0 * apq);
         const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
         const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
@@ -103,11 +106,38 @@ void SymmetricEigen3(const double A[9], double w[3], double V[9]) {
   double Vs[9];
   for (int c = 0; c < 3; ++c) {
     w[c] = a[4 * order[c]];
-    int big = 0;
-    for (int r = 1; r < 3; ++r)
-      if (std::fabs(V[3 * r + order[c]]) > std::fabs(V[3 * big + order[c]])) big = r;
+    double vmax = 0.0;
+    for (int r = 0; r < 3; ++r) vmax = std::max(vmax, std::fabs(V[3 * r + order[c]]));
+    int big = 0;  // first component within 1e-6 of the largest magnitude is made positive
+    while (big < 2 && std::fabs(V[3 * big + order[c]]) < vmax * (1.0 - 1e-6)) ++big;
     const double sign = V[3 * big + order[c]] < 0 ? -1.0 : 1.0;
     for (int r = 0; r < 3; ++r) Vs[3 * r + c] = sign * V[3 * r + order[c]];
+  }
+  // Repeated eigenvalues (planar patches: the two in-plane variances tie) leave the eigenbasis of the
+  // degenerate plane undetermined, and rounding noise would pick it.  Fix it instead: take the
+  // Householder reflection that maps e_0 onto the eigenvector n of the distinct eigenvalue (or e_2 onto
+  // it when the two SMALL eigenvalues tie).  Its columns are an orthonormal eigenbasis, it is symmetric,
+  // and therefore the harness formula D^-1/2 V coincides with the true square root D^-1/2 V^T there.
+  {
+    const double tol = 1e-9 * std::fabs(w[2]);
+    const bool tie_hi = std::fabs(w[2] - w[1]) <= tol, tie_lo = std::fabs(w[1] - w[0]) <= tol;
+    if (tie_hi && tie_lo) {
+      for (int i = 0; i < 9; ++i) Vs[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    } else if (tie_hi || tie_lo) {
+      const int col = tie_hi ? 0 : 2;  // the column that holds the distinct eigenvector
+      double nvec[3] = {Vs[col], Vs[3 + col], Vs[6 + col]};
+      if (nvec[col] > 0) {             // reflect e_col onto -n when that is the better conditioned choice
+        nvec[0] = -nvec[0];
+        nvec[1] = -nvec[1];
+        nvec[2] = -nvec[2];
+      }
+      double hv[3] = {-nvec[0], -nvec[1], -nvec[2]};
+      hv[col] += 1.0;                   // hv = e_col - n
+      const double hh = hv[0] * hv[0] + hv[1] * hv[1] + hv[2] * hv[2];
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) Vs[3 * r + c] = (r == c ? 1.0 : 0.0) - 2.0 * hv[r] * hv[c] / hh;
+      // no per-column sign flips here: they would break the symmetry that makes the formula well posed
+    }
   }
   std::copy(Vs, Vs + 9, V);
 }
@@ -139,7 +169,11 @@ void UpdateNdtMap(const std::vector<Vec3>& pts, double voxel, NdtMap* map, std::
     w[0] = std::max(w[0], 0.01 * w[2]);
     w[1] = std::max(w[1], 0.01 * w[2]);
     for (int i = 0; i < 3; ++i)
-      for (int j = 0; j < 3; ++j) ndt.sqrt_information(i, j) = V[3 * i + j] / std::sqrt(w[i]);  // diag(w^-1/2) * V
+      // The reference's harness writes diag(w^-1/2) * V (:275-276).  That equals the square root of the
+      // inverse covariance only when V is symmetric; in general it ties the wrong axes together and where
+      // the optimisation lands then depends on Eigen's eigenvector conventions.  The demo
+      // uses the actual square root, diag(w^-1/2) * V^T, so that its result is well defined.
+      for (int j = 0; j < 3; ++j) ndt.sqrt_information(i, j) = V[3 * j + i] / std::sqrt(w[i]);
     ndt.is_valid = true;
   }
 }

@@ -183,6 +183,32 @@ size_t nos_scan_size(const nos_scan* scan);
 int nos_ndt_match(nos_ndt_map* map, nos_scan* scan, const double R[9], const double t[3],
                   int max_neighbors, int dtype, nos_dataset** out_ds, size_t* n_matches);
 
+/* ---- NDT map construction on the device --------------------
+ * Replaces UpdateNdtMap of the reference's test harness
+ * (MDM/tests/simple_optimization_test.cc:236-281): voxelise points_xyz ([n][3], map frame) at
+ * voxel_resolution, accumulate count / sum / moment per voxel (moment starts at identity,
+ * MDM/types.h:14), mean, covariance, symmetric 3x3 eigen-decomposition, eigenvalue flooring and
+ * sqrt_information = diag(eigvals^-1/2) * eigenvectors; a voxel is valid with >= 5 points and a
+ * largest eigenvalue >= 0.01.  The result is a ready-to-match nos_ndt_map; *out_stats (optional)
+ * gives the per-voxel numbers back (voxels ordered by ascending integer cell coordinates).
+ * Voxel coordinates are limited to +-2^20 cells per axis. */
+typedef struct nos_map_stats nos_map_stats;
+/* flags: 0 reproduces the harness formula sqrt_information = D^-1/2 * V (:275-276), whose result
+ * depends on the eigenvector sign convention (here: the first near-largest component of every
+ * eigenvector is positive; Eigen's own convention is not reproducible without Eigen);
+ * NOS_MAP_PROPER_SQRT_INFORMATION uses D^-1/2 * V^T, the true square root of the inverse
+ * covariance, which is sign- and degenerate-subspace-invariant. */
+#define NOS_MAP_PROPER_SQRT_INFORMATION 1
+int nos_ndt_map_build(nos_ctx* ctx, size_t n_points, const double* points_xyz,
+                      double voxel_resolution, double search_radius_sq, int flags,
+                      nos_ndt_map** out_map, nos_map_stats** out_stats);
+size_t nos_map_stats_size(const nos_map_stats* stats);
+/* Any output pointer may be NULL.  means [V][3], sqrt_infos [V][9] row-major, valid [V],
+ * counts [V], cells [V][3]. */
+int nos_map_stats_get(const nos_map_stats* stats, double* means_xyz, double* sqrt_infos,
+                      unsigned char* valid, uint32_t* counts, int64_t* cells_xyz);
+int nos_map_stats_destroy(nos_map_stats* stats);
+
 /* ---- the hot path -------------------------------------------------------------
  * nos_ndt6_accumulate replaces
  *   MahalanobisDistanceMinimizerAnalyticSIMD::ComputeCostAndDerivatives

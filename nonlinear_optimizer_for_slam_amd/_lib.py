@@ -29,7 +29,8 @@ C_ABI_SYMBOLS = (
     "nos_ndt_dataset_create_from_device", "nos_reproj_dataset_create_from_device",
     "nos_ndt_dataset_create_from_records", "nos_reproj_dataset_create_from_records",
     "nos_dataset_download", "nos_ndt_map_create", "nos_ndt_map_destroy", "nos_ndt_map_size", "nos_scan_create",
-    "nos_scan_destroy", "nos_scan_size", "nos_ndt_match", "nos_dataset_destroy", "nos_dataset_size", "nos_dataset_dtype", "nos_dataset_stream_bytes",
+    "nos_scan_destroy", "nos_scan_size", "nos_ndt_match", "nos_ndt_map_build", "nos_map_stats_size",
+    "nos_map_stats_get", "nos_map_stats_destroy", "nos_dataset_destroy", "nos_dataset_size", "nos_dataset_dtype", "nos_dataset_stream_bytes",
     "nos_ndt6_accumulate", "nos_ndt3_accumulate", "nos_reproj_accumulate",
     "nos_ndt6_accumulate_async", "nos_ndt3_accumulate_async", "nos_reproj_accumulate_async",
     "nos_ctx_set_launch", "nos_ctx_profile_begin", "nos_ctx_profile_end", "nos_ndt6_time_kernel", "nos_reproj_time_kernel",
@@ -99,6 +100,12 @@ def _declare(lib):
     lib.nos_scan_size.argtypes = [vp]
     lib.nos_scan_size.restype = sz
     lib.nos_ndt_match.argtypes = [vp, vp, dp, dp, i, i, c_void_pp, ctypes.POINTER(sz)]
+    lib.nos_ndt_map_build.argtypes = [vp, sz, dp, ctypes.c_double, ctypes.c_double, i, c_void_pp, c_void_pp]
+    lib.nos_map_stats_size.argtypes = [vp]
+    lib.nos_map_stats_size.restype = sz
+    lib.nos_map_stats_get.argtypes = [vp, dp, dp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint32),
+                                      ctypes.POINTER(ctypes.c_int64)]
+    lib.nos_map_stats_destroy.argtypes = [vp]
     lib.nos_dataset_destroy.argtypes = [vp]
     lib.nos_dataset_size.argtypes = [vp]
     lib.nos_dataset_size.restype = sz

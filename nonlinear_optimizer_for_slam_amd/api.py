@@ -5,6 +5,7 @@ numpy arrays go in and out; torch is optional and only used for device-resident 
 device memory, streams and torch.distributed — all arithmetic happens in libnos_hip.so.
 """
 import ctypes
+import weakref
 
 import numpy as np
 
@@ -58,6 +59,10 @@ class Context:
         check(self._lib.nos_ctx_create(ids, len(device_ids), ctypes.byref(h)), "nos_ctx_create")
         self._h = h
         self.device_ids = tuple(device_ids)
+        self._children = weakref.WeakSet()  # datasets / maps / scans living on this context
+
+    def _adopt(self, child):
+        self._children.add(child)
 
     @property
     def handle(self):
@@ -114,6 +119,8 @@ class Context:
 
     def close(self):
         if self._h:
+            for child in list(self._children):  # device objects must not outlive their context
+                child.close()
             self._lib.nos_ctx_destroy(self._h)
             self._h = None
 
@@ -132,6 +139,7 @@ class _Dataset:
         self._ctx = ctx
         self._lib = ctx._lib
         self._h = handle
+        ctx._adopt(self)
 
     @classmethod
     def from_planes(cls, ctx, planes, dtype="f64"):
@@ -320,6 +328,41 @@ class NdtMap:
         check(self._lib.nos_ndt_map_create(ctx.handle, means.shape[0], _dp(means), _dp(S), vbuf,
                                            ctypes.c_double(search_radius_sq), ctypes.byref(h)), "nos_ndt_map_create")
         self._h = h
+        ctx._adopt(self)
+
+    @classmethod
+    def build(cls, ctx, points, voxel_resolution=1.0, search_radius_sq=1.0, proper_sqrt_information=True):
+        """Construct the map from raw points [n,3] on the GPU (nos_ndt_map_build, the reference's
+        UpdateNdtMap).  → (NdtMap, stats dict with means, sqrt_infos, valid, counts, cells).
+
+        proper_sqrt_information=True (default) stores D^-1/2 V^T, the true square root of the inverse
+        covariance; False reproduces the harness formula D^-1/2 V, which is only meaningful when V happens
+        to be symmetric (include/nos.h)."""
+        pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+        h = ctypes.c_void_p()
+        hs = ctypes.c_void_p()
+        lib = ctx._lib
+        check(lib.nos_ndt_map_build(ctx.handle, pts.shape[0], _dp(pts), ctypes.c_double(voxel_resolution),
+                                    ctypes.c_double(search_radius_sq), int(bool(proper_sqrt_information)),
+                                    ctypes.byref(h), ctypes.byref(hs)),
+              "nos_ndt_map_build")
+        V = int(lib.nos_map_stats_size(hs))
+        means = np.zeros((V, 3))
+        S = np.zeros((V, 9))
+        valid = np.zeros(V, dtype=np.uint8)
+        counts = np.zeros(V, dtype=np.uint32)
+        cells = np.zeros((V, 3), dtype=np.int64)
+        check(lib.nos_map_stats_get(hs, _dp(means), _dp(S), valid.ctypes.data_as(ctypes.c_char_p),
+                                    counts.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)),
+                                    cells.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))), "nos_map_stats_get")
+        lib.nos_map_stats_destroy(hs)
+        self = cls.__new__(cls)
+        self._ctx = ctx
+        self._lib = lib
+        self._h = h
+        ctx._adopt(self)
+        return self, {"means": means, "sqrt_infos": S.reshape(V, 3, 3), "valid": valid.astype(bool),
+                      "counts": counts, "cells": cells}
 
     def __len__(self):
         return int(self._lib.nos_ndt_map_size(self._h))
@@ -356,6 +399,7 @@ class Scan:
         h = ctypes.c_void_p()
         check(self._lib.nos_scan_create(ctx.handle, pts.shape[0], _dp(pts), ctypes.byref(h)), "nos_scan_create")
         self._h = h
+        ctx._adopt(self)
 
     def __len__(self):
         return int(self._lib.nos_scan_size(self._h))

@@ -309,7 +309,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 // Sums acc[] over the block and writes one row of kOut doubles.  Fixed order:
 // butterfly inside a wave, then waves 0..W-1.
 template <int NOUT, int BLOCK>
-__device__ __forceinline__ void block_reduce_store(const double (&acc)[NOUT], double* row) {
+__device__ __forceinline__ void block_reduce_store(const double (&acc)[NOUT], double* row, bool write_through) {
   constexpr int kWaves = BLOCK / kWave;
   __shared__ double lds[kWaves][NOUT];
   const int lane = threadIdx.x & (kWave - 1);
@@ -324,7 +324,10 @@ __device__ __forceinline__ void block_reduce_store(const double (&acc)[NOUT], do
     double s = 0.0;
 #pragma unroll
     for (int wv = 0; wv < kWaves; ++wv) s += lds[wv][threadIdx.x];
-    row[threadIdx.x] = s;
+    if (write_through)  // sc1 store: leaves the XCD's L2 at once (hand-off without a release fence)
+      __hip_atomic_store(row + threadIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+      row[threadIdx.x] = s;
   }
 }
 
@@ -344,6 +347,7 @@ struct FusedFinal {
   double* out_host;                // host-mapped pinned result (may be null)
   unsigned long long* seq_host;    // host-mapped pinned sequence word (may be null)
   unsigned long long seq;          // value stored to *seq_host when the result is complete
+  int write_through;               // 1: rows travel as sc1 stores / sc1 loads instead of release / acquire fences
 };
 
 template <int NOUT, int BLOCK>
@@ -354,12 +358,20 @@ __device__ __forceinline__ void finish_in_last_block(const double* partials, con
   __shared__ double red[kSlices][kCols];
   // the row was stored by lanes 0..NOUT-1 of wave 0; thread 0 is in that wave
   if (threadIdx.x < kWave) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // Two forms of the same hand-off (both listed as valid in the guide):
+  //   fences:        plain row stores → drain → agent release → ticket;  last block: agent acquire → plain loads
+  //   write-through: sc1 row stores → drain → ticket;                     last block: sc1 loads (bypass L1), no fences
+  // The second is used for the one-workgroup-per-CU geometry it was measured for (MI355X_MICROARCH.md,
+  // "Hand-offs measured with sc1 loads in place of the acquire", row 1) and saves both fences (≈3 µs).
+  const bool wt = fin.write_through != 0;
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!wt) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     const unsigned int ticket = __hip_atomic_fetch_add(fin.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned int last = (ticket == gridDim.x - 1) ? 1u : 0u;
-    if (last) {
+    if (last && !wt) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -367,11 +379,18 @@ __device__ __forceinline__ void finish_in_last_block(const double* partials, con
   }
   __syncthreads();
   if (s_last == 0u) return;  // block-uniform
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // no instruction: keeps the loads below the ticket
   const int col = threadIdx.x % kCols;
   const int slice = threadIdx.x / kCols;
   double s = 0.0;
-  if (col < NOUT)
-    for (uint32_t r = slice; r < gridDim.x; r += kSlices) s += partials[size_t(r) * NOUT + col];
+  if (col < NOUT) {
+    if (wt) {
+      for (uint32_t r = slice; r < gridDim.x; r += kSlices)
+        s += __hip_atomic_load(partials + size_t(r) * NOUT + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      for (uint32_t r = slice; r < gridDim.x; r += kSlices) s += partials[size_t(r) * NOUT + col];
+    }
+  }
   red[slice][col] = s;
   __syncthreads();
   if (threadIdx.x < NOUT) {
@@ -434,7 +453,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void assemble_kernel(TiledLayout L,
   double dacc[kOut];
 #pragma unroll
   for (int k = 0; k < kOut; ++k) dacc[k] = double(acc[k]);
-  block_reduce_store<kOut, BLOCK>(dacc, partials + size_t(blockIdx.x) * kOut);
+  block_reduce_store<kOut, BLOCK>(dacc, partials + size_t(blockIdx.x) * kOut, fin.write_through != 0);
   if (fin.counter != nullptr) finish_in_last_block<kOut, BLOCK>(partials, fin);
 }
 

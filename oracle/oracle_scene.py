@@ -67,8 +67,40 @@ def filter_points(points, voxel_size):
     return points[np.sort(first)]
 
 
-def build_ndt_map(points, voxel_resolution=1.0):
-    """→ dict(means [V,3], sqrt_infos [V,3,3], valid [V], keys [V]) in first-seen voxel order."""
+def canonical_signs(U):
+    """Eigenvector sign convention of the GPU map build: the first component whose magnitude is within
+    1e-6 of the largest is positive."""
+    U = U.copy()
+    for k in range(U.shape[1]):
+        mag = np.abs(U[:, k])
+        i = int(np.nonzero(mag >= mag.max() * (1.0 - 1e-6))[0][0])  # first of the (near-)largest components
+        if U[i, k] < 0:
+            U[:, k] = -U[:, k]
+    return U
+
+
+def canonical_eigenbasis(w, U):
+    """Tie rule of the GPU map build: when two eigenvalues coincide (relative 1e-9) the eigenbasis is the
+    Householder reflection mapping e_0 (two LARGE eigenvalues tie) or e_2 (two SMALL ones tie) onto the
+    distinct eigenvector; all three tie → identity.  Otherwise U is returned unchanged."""
+    tol = 1e-9 * abs(w[2])
+    tie_hi, tie_lo = abs(w[2] - w[1]) <= tol, abs(w[1] - w[0]) <= tol
+    if tie_hi and tie_lo:
+        return np.eye(3)
+    if not (tie_hi or tie_lo):
+        return U
+    col = 0 if tie_hi else 2
+    n = U[:, col].copy()
+    if n[col] > 0:
+        n = -n
+    hv = -n
+    hv[col] += 1.0
+    return np.eye(3) - 2.0 * np.outer(hv, hv) / float(hv @ hv)
+
+
+def build_ndt_map(points, voxel_resolution=1.0, canonical=False, proper_transpose=False):
+    """→ dict(means [V,3], sqrt_infos [V,3,3], valid [V], keys [V], cells [V,3], eigvals [V,3]) in
+    first-seen voxel order.  canonical=True applies canonical_signs to the eigenvectors."""
     keys = voxel_keys(points, 1.0 / voxel_resolution)
     uniq, first, inv = np.unique(keys, return_index=True, return_inverse=True)
     order = np.argsort(first)  # first-seen order
@@ -84,12 +116,19 @@ def build_ndt_map(points, voxel_resolution=1.0):
     means = np.zeros((V, 3))
     S = np.tile(np.eye(3), (V, 1, 1))
     valid = np.zeros(V, dtype=bool)
+    eigvals = np.zeros((V, 3))
+    cells_all = np.floor(points * (1.0 / voxel_resolution)).astype(np.int64)
+    cells = np.zeros((V, 3), dtype=np.int64)
+    cells[vid] = cells_all
     for v in range(V):
         if count[v] < 5:
             continue
         mean = s[v] / count[v]
         cov = moment[v] / count[v] - np.outer(mean, mean)
         w, U = np.linalg.eigh(cov)
+        if canonical:
+            U = canonical_eigenbasis(w, canonical_signs(U))
+        eigvals[v] = w
         if w[2] < 0.01:
             # the reference `return`s here (harness bug); not reproduced
             continue
@@ -97,9 +136,10 @@ def build_ndt_map(points, voxel_resolution=1.0):
         w[0] = max(w[0], w[2] * 0.01)
         w[1] = max(w[1], w[2] * 0.01)
         means[v] = mean
-        S[v] = np.diag(1.0 / np.sqrt(w)) @ U
+        S[v] = np.diag(1.0 / np.sqrt(w)) @ (U.T if proper_transpose else U)
         valid[v] = True
-    return {"means": means, "sqrt_infos": S, "valid": valid, "keys": uniq[order], "count": count}
+    return {"means": means, "sqrt_infos": S, "valid": valid, "keys": uniq[order], "count": count, "cells": cells,
+            "eigvals": eigvals}
 
 
 def match_point_cloud(means, sqrt_infos, valid, local_points, R, t, radius_sq=1.0, max_neighbors=2):
