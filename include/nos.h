@@ -246,6 +246,39 @@ int nos_reproj_accumulate_async(nos_dataset* ds, const double R[9], const double
                                 const double intr[4], const nos_loss* loss, double min_depth,
                                 double* d_out28);
 
+/* ---- pose-graph optimisation (BASELINE.json configs[4]) --------
+ * The reference's PoseGraphOptimizerAnalytic::Solve is an empty loop
+ * (NO/pose_graph_optimizer/pose_graph_optimizer_analytic.cc:12-51); only the Ceres path is real.
+ * These entry points provide what its TODO comments ask for (:36-42 "Make sparse Hessian / Solve
+ * normal equation / Update poses / Check convergence") for the residual Ceres minimises
+ * (NO/pose_graph_optimizer/ceres_cost_functor.h:17-53, switchable :55-98):
+ *   r_t = (p_q - p_r) - q_r (x) t_m,  r_R = 2 vec(q_q^* q_r q_m);  loop constraints: r <- s r and a
+ *   seventh residual (1 - s) * 1e-9 with a free switch s.
+ * poses [n][7] = px py pz qw qx qy qz (PoseParameter, pose_graph_optimizer.h:16-19);
+ * meas [m][7] = relative_pose_from_reference_to_query, same packing (types.h:13-19);
+ * switch_init / switch_free / fixed may be NULL.  One Gauss-Newton / LM iteration is
+ *   nos_pgo_linearize → nos_pgo_solve (block-Jacobi PCG on the damped normal equations, matrix
+ *   free) → nos_pgo_retract (p += dp, q = normalize(q (x) Exp(dw)), s += ds).
+ * The normal matrix is never stored: every sweep re-derives the per-constraint Jacobian blocks
+ * from the poses ("owner computes", no atomics, bit-reproducible).  Single-device contexts. */
+typedef struct nos_pose_graph nos_pose_graph;
+int nos_pgo_create(nos_ctx* ctx, size_t n_poses, const double* poses, size_t n_edges,
+                   const int32_t* ref, const int32_t* qry, const double* meas,
+                   const double* switch_init, const unsigned char* switch_free,
+                   const unsigned char* fixed, nos_pose_graph** out_pg);
+int nos_pgo_destroy(nos_pose_graph* pg);
+size_t nos_pgo_num_unknowns(const nos_pose_graph* pg); /* 6 n_poses + n_edges */
+int nos_pgo_linearize(nos_pose_graph* pg, double* cost, double* gradient_norm);
+int nos_pgo_solve(nos_pose_graph* pg, double lambda, int max_iterations, double rel_tolerance,
+                  int* iterations, double* rel_residual, double* step_norm);
+int nos_pgo_retract(nos_pose_graph* pg);
+int nos_pgo_get_state(nos_pose_graph* pg, double* poses, double* switches);
+/* which: 0 gradient, 1 last step (both 6 planes of n_poses then n_edges switch entries),
+ * 2 diagonal blocks (21 planes of n_poses, upper triangle row-major).  Diagnostics. */
+int nos_pgo_get_vector(nos_pose_graph* pg, int which, double* out);
+/* y = (J^T J with its diagonal scaled by 1 + lambda) x for host vectors.  Diagnostics. */
+int nos_pgo_matvec(nos_pose_graph* pg, double lambda, const double* x, double* y);
+
 /* ---- measurement / diagnostics ------------------------------------------------- */
 /* Launch geometry override (0 = library default): blocks per CU of the assemble grid and
  * the index of the compiled kernel geometry.  Tuning knob, not needed for normal use. */

@@ -30,7 +30,9 @@ C_ABI_SYMBOLS = (
     "nos_ndt_dataset_create_from_records", "nos_reproj_dataset_create_from_records",
     "nos_dataset_download", "nos_ndt_map_create", "nos_ndt_map_destroy", "nos_ndt_map_size", "nos_scan_create",
     "nos_scan_destroy", "nos_scan_size", "nos_ndt_match", "nos_ndt_map_build", "nos_map_stats_size",
-    "nos_map_stats_get", "nos_map_stats_destroy", "nos_dataset_destroy", "nos_dataset_size", "nos_dataset_dtype", "nos_dataset_stream_bytes",
+    "nos_map_stats_get", "nos_map_stats_destroy", "nos_pgo_create", "nos_pgo_destroy", "nos_pgo_num_unknowns",
+    "nos_pgo_linearize", "nos_pgo_solve", "nos_pgo_retract", "nos_pgo_get_state", "nos_pgo_get_vector",
+    "nos_pgo_matvec", "nos_dataset_destroy", "nos_dataset_size", "nos_dataset_dtype", "nos_dataset_stream_bytes",
     "nos_ndt6_accumulate", "nos_ndt3_accumulate", "nos_reproj_accumulate",
     "nos_ndt6_accumulate_async", "nos_ndt3_accumulate_async", "nos_reproj_accumulate_async",
     "nos_ctx_set_launch", "nos_ctx_profile_begin", "nos_ctx_profile_end", "nos_ndt6_time_kernel", "nos_reproj_time_kernel",
@@ -106,6 +108,17 @@ def _declare(lib):
     lib.nos_map_stats_get.argtypes = [vp, dp, dp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint32),
                                       ctypes.POINTER(ctypes.c_int64)]
     lib.nos_map_stats_destroy.argtypes = [vp]
+    ip = ctypes.POINTER(ctypes.c_int32)
+    lib.nos_pgo_create.argtypes = [vp, sz, dp, sz, ip, ip, dp, dp, ctypes.c_char_p, ctypes.c_char_p, c_void_pp]
+    lib.nos_pgo_destroy.argtypes = [vp]
+    lib.nos_pgo_num_unknowns.argtypes = [vp]
+    lib.nos_pgo_num_unknowns.restype = sz
+    lib.nos_pgo_linearize.argtypes = [vp, dp, dp]
+    lib.nos_pgo_solve.argtypes = [vp, ctypes.c_double, i, ctypes.c_double, ctypes.POINTER(i), dp, dp]
+    lib.nos_pgo_retract.argtypes = [vp]
+    lib.nos_pgo_get_state.argtypes = [vp, dp, dp]
+    lib.nos_pgo_get_vector.argtypes = [vp, i, dp]
+    lib.nos_pgo_matvec.argtypes = [vp, ctypes.c_double, dp, dp]
     lib.nos_dataset_destroy.argtypes = [vp]
     lib.nos_dataset_size.argtypes = [vp]
     lib.nos_dataset_size.restype = sz

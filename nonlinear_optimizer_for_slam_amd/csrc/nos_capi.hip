@@ -1564,3 +1564,5 @@ int nos_ndt_map_build(nos_ctx* ctx, size_t n_points, const double* points_xyz, d
 }
 
 }  // extern "C"
+
+#include "nos_pgo.inc"

@@ -1,0 +1,535 @@
+// pgo_kernels.hpp — pose-graph optimisation on the GPU (BASELINE.json configs[4]).
+//
+// Residual of one relative-pose constraint (reference: nonlinear_optimizer/pose_graph_optimizer/
+// ceres_cost_functor.h:44-51; switchable form :83-94):
+//     r_t = (p_q - p_r) - q_r (x) t_m
+//     r_R = 2 vec( q_q^* (x) q_r (x) q_m )
+//     loop constraints:  r <- s r,  r_7 = (1 - s) * 1e-9   with a free switch variable s
+// The reference evaluates this through Ceres autodiff only — its analytic solver is an empty loop
+// (pose_graph_optimizer_analytic.cc:21-42, "Make sparse Hessian / Solve normal equation using Sparse
+// Cholesky / Update poses" are TODO comments).  Here the Jacobians are analytic, under the same
+// right-multiplicative update the other analytic solvers use (p <- p + dp, q <- q (x) Exp(dw)):
+//     d r / d x_r = [ -I   R_r [t_m]x              ]      d r / d x_q = [ I   0                ]
+//                   [  0   (e_w I + [e_v]x) R_m^T  ]                    [ 0   -e_w I + [e_v]x  ]
+// with e = q_q^* q_r q_m.
+//
+// MI355X mapping: the normal matrix is block sparse (6x6 block per pose, one per constraint).  Nothing
+// of it is stored except the diagonal blocks: every sweep is "owner computes" — one lane per pose walks
+// that pose's incident constraints (CSR adjacency built once), gathers the neighbour pose, re-derives
+// the 3x3 Jacobian blocks in registers and accumulates its own row.  No atomics, no scatter, results
+// bit-reproducible; poses (56 B) and vectors (48 B) of a million-pose graph stay in the Infinity
+// Cache, so the sweeps are fp64-ALU / latency bound rather than HBM bound.  The damped system is solved
+// by block-Jacobi preconditioned CG built from three such sweeps per iteration.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "assemble_kernels.hpp"
+
+namespace nos {
+
+constexpr double kSwitchPrior = 1e-9;  // ceres_cost_functor.h:93
+
+struct PgoView {
+  // poses, SoA
+  const double* p[3];
+  const double* q[4];  // w x y z
+  // constraints, SoA
+  const int32_t* ref;
+  const int32_t* qry;
+  const double* tm[3];
+  const double* qm[4];
+  const double* sw;            // current switch value per constraint (1 for odometry)
+  const uint8_t* sw_free;      // 1: the switch is an optimisation variable (loop constraints)
+  // adjacency: constraints incident to pose i are adj[adj_off[i] .. adj_off[i+1]); entry = 2*edge + role
+  // (role 0: pose is the reference end, 1: the query end)
+  const uint32_t* adj_off;
+  const uint32_t* adj;
+  const uint8_t* fixed;        // per pose
+  uint32_t n_poses;
+  uint32_t n_edges;
+};
+
+struct Quat4 {
+  double w, x, y, z;
+};
+
+__device__ __forceinline__ Quat4 qmul(const Quat4& a, const Quat4& b) {
+  return {a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+          a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z, a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x};
+}
+
+__device__ __forceinline__ void qrot_matrix(const Quat4& q, double R[9]) {
+  const double tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z;
+  const double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
+  const double txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
+  const double tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+  R[0] = 1 - (tyy + tzz);
+  R[1] = txy - twz;
+  R[2] = txz + twy;
+  R[3] = txy + twz;
+  R[4] = 1 - (txx + tzz);
+  R[5] = tyz - twx;
+  R[6] = txz - twy;
+  R[7] = tyz + twx;
+  R[8] = 1 - (txx + tyy);
+}
+
+// Everything one constraint contributes, in registers.
+struct EdgeTerms {
+  double r[6];   // unscaled residual (r_t, r_R)
+  double A[9];   // R_r [t_m]x                      (d r_t / d w_r)
+  double B[9];   // (e_w I + [e_v]x) R_m^T          (d r_R / d w_r)
+  double C[9];   // -e_w I + [e_v]x                 (d r_R / d w_q)
+};
+
+__device__ __forceinline__ void edge_terms(const PgoView& G, uint32_t e, EdgeTerms& T) {
+  const int32_t ir = G.ref[e], iq = G.qry[e];
+  const Quat4 qr{G.q[0][ir], G.q[1][ir], G.q[2][ir], G.q[3][ir]};
+  const Quat4 qq{G.q[0][iq], G.q[1][iq], G.q[2][iq], G.q[3][iq]};
+  const Quat4 qm{G.qm[0][e], G.qm[1][e], G.qm[2][e], G.qm[3][e]};
+  const double tm[3] = {G.tm[0][e], G.tm[1][e], G.tm[2][e]};
+  double Rr[9], Rm[9];
+  qrot_matrix(qr, Rr);
+  qrot_matrix(qm, Rm);
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    T.r[i] = (G.p[i][iq] - G.p[i][ir]) - (Rr[3 * i] * tm[0] + Rr[3 * i + 1] * tm[1] + Rr[3 * i + 2] * tm[2]);
+  const Quat4 qqc{qq.w, -qq.x, -qq.y, -qq.z};
+  const Quat4 eq = qmul(qmul(qqc, qr), qm);
+  T.r[3] = 2 * eq.x;
+  T.r[4] = 2 * eq.y;
+  T.r[5] = 2 * eq.z;
+  // A = R_r [t_m]x : column j = R_r (e_j-th column of [t]x);  [t]x = [0 -tz ty; tz 0 -tx; -ty tx 0]
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    T.A[3 * i + 0] = Rr[3 * i + 1] * tm[2] - Rr[3 * i + 2] * tm[1];
+    T.A[3 * i + 1] = Rr[3 * i + 2] * tm[0] - Rr[3 * i + 0] * tm[2];
+    T.A[3 * i + 2] = Rr[3 * i + 0] * tm[1] - Rr[3 * i + 1] * tm[0];
+  }
+  // E+ = e_w I + [e_v]x ,  E- = -e_w I + [e_v]x
+  const double Ep[9] = {eq.w, -eq.z, eq.y, eq.z, eq.w, -eq.x, -eq.y, eq.x, eq.w};
+  T.C[0] = -eq.w;
+  T.C[1] = -eq.z;
+  T.C[2] = eq.y;
+  T.C[3] = eq.z;
+  T.C[4] = -eq.w;
+  T.C[5] = -eq.x;
+  T.C[6] = -eq.y;
+  T.C[7] = eq.x;
+  T.C[8] = -eq.w;
+  // B = E+ R_m^T
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      T.B[3 * i + j] = Ep[3 * i] * Rm[3 * j] + Ep[3 * i + 1] * Rm[3 * j + 1] + Ep[3 * i + 2] * Rm[3 * j + 2];
+}
+
+// y = J_role x  (6-vector) for the unscaled Jacobian of the given role.
+__device__ __forceinline__ void apply_J(const EdgeTerms& T, int role, const double x[6], double y[6]) {
+  if (role == 0) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      y[i] = -x[i] + T.A[3 * i] * x[3] + T.A[3 * i + 1] * x[4] + T.A[3 * i + 2] * x[5];
+      y[3 + i] = T.B[3 * i] * x[3] + T.B[3 * i + 1] * x[4] + T.B[3 * i + 2] * x[5];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      y[i] = x[i];
+      y[3 + i] = T.C[3 * i] * x[3] + T.C[3 * i + 1] * x[4] + T.C[3 * i + 2] * x[5];
+    }
+  }
+}
+
+// out += scale * J_role^T y
+__device__ __forceinline__ void add_JT(const EdgeTerms& T, int role, const double y[6], double scale, double out[6]) {
+  if (role == 0) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      out[j] += scale * (-y[j]);
+      out[3 + j] += scale * (T.A[j] * y[0] + T.A[3 + j] * y[1] + T.A[6 + j] * y[2] + T.B[j] * y[3] + T.B[3 + j] * y[4] +
+                             T.B[6 + j] * y[5]);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      out[j] += scale * y[j];
+      out[3 + j] += scale * (T.C[j] * y[3] + T.C[3 + j] * y[4] + T.C[6 + j] * y[5]);
+    }
+  }
+}
+
+// Linearisation sweep.  Per pose: H_ii (21 upper, row-major) and g_i; per launch: the cost
+// (sum over constraints of |s r|^2 + (1-s)^2 c^2, counted at the reference end) as block partials.
+// hdiag: 21 planes of n_poses, grad: 6 planes of n_poses.
+__global__ __launch_bounds__(256) void pgo_linearize_kernel(PgoView G, double* __restrict__ hdiag,
+                                                            double* __restrict__ grad,
+                                                            double* __restrict__ cost_partials) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  double cost = 0.0;
+  if (i < G.n_poses) {
+    double H[21], g[6];
+#pragma unroll
+    for (int k = 0; k < 21; ++k) H[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) g[k] = 0.0;
+    const bool fixed = G.fixed[i] != 0;
+    for (uint32_t a = G.adj_off[i]; a < G.adj_off[i + 1]; ++a) {
+      const uint32_t e = G.adj[a] >> 1;
+      const int role = int(G.adj[a] & 1u);
+      EdgeTerms T;
+      edge_terms(G, e, T);
+      const double s = G.sw[e];
+      if (role == 0) {
+        double rr = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) rr += T.r[k] * T.r[k];
+        cost += s * s * rr;
+        if (G.sw_free[e]) cost += (1.0 - s) * (1.0 - s) * kSwitchPrior * kSwitchPrior;
+      }
+      if (fixed) continue;
+      // g_i += (s J)^T (s r)
+      add_JT(T, role, T.r, s * s, g);
+      // H_ii += s^2 J^T J, column by column of J
+      double Jcol[6][6];  // Jcol[c] = J e_c
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        double ec[6] = {0, 0, 0, 0, 0, 0};
+        ec[c] = 1.0;
+        apply_J(T, role, ec, Jcol[c]);
+      }
+      int k = 0;
+#pragma unroll
+      for (int r0 = 0; r0 < 6; ++r0)
+#pragma unroll
+        for (int c0 = r0; c0 < 6; ++c0) {
+          double d = 0.0;
+#pragma unroll
+          for (int m = 0; m < 6; ++m) d += Jcol[r0][m] * Jcol[c0][m];
+          H[k++] += s * s * d;
+        }
+    }
+    if (fixed) {  // identity block keeps the system SPD; the gradient of a fixed pose is zero
+      const int dg[6] = {0, 6, 11, 15, 18, 20};
+#pragma unroll
+      for (int k = 0; k < 6; ++k) H[dg[k]] = 1.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 21; ++k) hdiag[size_t(k) * G.n_poses + i] = H[k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) grad[size_t(k) * G.n_poses + i] = g[k];
+  }
+  // cost: block sum in fixed order
+  __shared__ double lds[4];
+  const double ws = wave_sum(cost);
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = ws;
+  __syncthreads();
+  if (threadIdx.x == 0) cost_partials[blockIdx.x] = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+}
+
+// Switch variables (one lane per constraint): gradient s |r|^2 - c^2 (1 - s) and curvature |r|^2 + c^2.
+__global__ __launch_bounds__(256) void pgo_switch_linearize_kernel(PgoView G, double* __restrict__ g_s,
+                                                                   double* __restrict__ h_s) {
+  const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= G.n_edges) return;
+  if (!G.sw_free[e]) {
+    g_s[e] = 0.0;
+    h_s[e] = 1.0;
+    return;
+  }
+  EdgeTerms T;
+  edge_terms(G, e, T);
+  double rr = 0.0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) rr += T.r[k] * T.r[k];
+  const double s = G.sw[e];
+  g_s[e] = s * rr - kSwitchPrior * kSwitchPrior * (1.0 - s);
+  h_s[e] = rr + kSwitchPrior * kSwitchPrior;
+}
+
+// y = (H + lambda diag(H)) x for the pose rows, matrix free.  x / y: 6 planes of n_poses; xs: per-constraint
+// switch components (0 where the switch is not free).
+__global__ __launch_bounds__(256) void pgo_matvec_pose_kernel(PgoView G, const double* __restrict__ hdiag,
+                                                              double lambda, const double* __restrict__ x,
+                                                              const double* __restrict__ xs,
+                                                              double* __restrict__ y) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= G.n_poses) return;
+  const size_t N = G.n_poses;
+  double xi[6], out[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) xi[k] = x[size_t(k) * N + i];
+  if (G.fixed[i]) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) y[size_t(k) * N + i] = (1.0 + lambda) * xi[k];
+    return;
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) out[k] = 0.0;
+  for (uint32_t a = G.adj_off[i]; a < G.adj_off[i + 1]; ++a) {
+    const uint32_t e = G.adj[a] >> 1;
+    const int role = int(G.adj[a] & 1u);
+    const uint32_t j = uint32_t(role == 0 ? G.qry[e] : G.ref[e]);
+    EdgeTerms T;
+    edge_terms(G, e, T);
+    const double s = G.sw[e];
+    double xj[6], v[6], vj[6];
+    const bool jfixed = G.fixed[j] != 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) xj[k] = jfixed ? 0.0 : x[size_t(k) * N + j];
+    apply_J(T, role, xi, v);
+    apply_J(T, 1 - role, xj, vj);
+    const double xse = G.sw_free[e] ? xs[e] : 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) v[k] = s * (v[k] + vj[k]) + T.r[k] * xse;  // (J_full x) restricted to the 6 rows
+    add_JT(T, role, v, s, out);
+  }
+  const int dg[6] = {0, 6, 11, 15, 18, 20};
+#pragma unroll
+  for (int k = 0; k < 6; ++k) y[size_t(k) * N + i] = out[k] + lambda * hdiag[size_t(dg[k]) * N + i] * xi[k];
+}
+
+// Switch rows of the same product.
+__global__ __launch_bounds__(256) void pgo_matvec_switch_kernel(PgoView G, const double* __restrict__ h_s, double lambda,
+                                                                const double* __restrict__ x,
+                                                                const double* __restrict__ xs,
+                                                                double* __restrict__ ys) {
+  const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= G.n_edges) return;
+  if (!G.sw_free[e]) {
+    ys[e] = (1.0 + lambda) * xs[e];
+    return;
+  }
+  const size_t N = G.n_poses;
+  const uint32_t ir = uint32_t(G.ref[e]), iq = uint32_t(G.qry[e]);
+  EdgeTerms T;
+  edge_terms(G, e, T);
+  double xr[6], xq[6], vr[6], vq[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    xr[k] = G.fixed[ir] ? 0.0 : x[size_t(k) * N + ir];
+    xq[k] = G.fixed[iq] ? 0.0 : x[size_t(k) * N + iq];
+  }
+  apply_J(T, 0, xr, vr);
+  apply_J(T, 1, xq, vq);
+  const double s = G.sw[e];
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) acc += T.r[k] * (s * (vr[k] + vq[k]));
+  ys[e] = acc + h_s[e] * (1.0 + lambda) * xs[e];
+}
+
+// Block-Jacobi preconditioner: inverse of the damped 6x6 diagonal block (Cholesky), stored as 21 upper
+// entries of the symmetric inverse.
+__global__ __launch_bounds__(256) void pgo_precond_kernel(const double* __restrict__ hdiag, double lambda, uint32_t n,
+                                                          double* __restrict__ minv) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double A[6][6];
+  int k = 0;
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int c = r; c < 6; ++c) {
+      const double v = hdiag[size_t(k++) * n + i];
+      A[r][c] = v;
+      A[c][r] = v;
+    }
+#pragma unroll
+  for (int r = 0; r < 6; ++r) A[r][r] *= 1.0 + lambda;
+  // Cholesky A = L L^T (in place, lower)
+  double L[6][6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) L[r][c] = 0.0;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    double d = A[j][j];
+#pragma unroll
+    for (int m = 0; m < 6; ++m)
+      if (m < j) d -= L[j][m] * L[j][m];
+    d = d > 1e-300 ? d : 1e-300;
+    const double lj = sqrt(d);
+    L[j][j] = lj;
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+      if (r > j) {
+        double v = A[r][j];
+#pragma unroll
+        for (int m = 0; m < 6; ++m)
+          if (m < j) v -= L[r][m] * L[j][m];
+        L[r][j] = v / lj;
+      }
+  }
+  // inverse of L (lower), then A^-1 = L^-T L^-1
+  double Li[6][6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) Li[r][c] = 0.0;
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    Li[c][c] = 1.0 / L[c][c];
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+      if (r > c) {
+        double v = 0.0;
+#pragma unroll
+        for (int m = 0; m < 6; ++m)
+          if (m >= c && m < r) v -= L[r][m] * Li[m][c];
+        Li[r][c] = v / L[r][r];
+      }
+  }
+  k = 0;
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int c = r; c < 6; ++c) {
+      double v = 0.0;
+#pragma unroll
+      for (int m = 0; m < 6; ++m)
+        if (m >= c) v += Li[m][r] * Li[m][c];
+      minv[size_t(k++) * n + i] = v;
+    }
+}
+
+// z = M^-1 r on pose rows and switch rows, plus block partials of r.z and r.r.
+// partials: [gridDim.x][2]
+__global__ __launch_bounds__(256) void pgo_apply_precond_kernel(const double* __restrict__ minv,
+                                                                const double* __restrict__ h_s, double lambda,
+                                                                uint32_t n_poses, uint32_t n_edges,
+                                                                const double* __restrict__ r,
+                                                                const double* __restrict__ rs, double* __restrict__ z,
+                                                                double* __restrict__ zs,
+                                                                double* __restrict__ partials) {
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  double rz = 0.0, rr = 0.0;
+  if (t < n_poses) {
+    double ri[6], M[6][6];
+    int k = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) ri[a] = r[size_t(a) * n_poses + t];
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int b = a; b < 6; ++b) {
+        const double v = minv[size_t(k++) * n_poses + t];
+        M[a][b] = v;
+        M[b][a] = v;
+      }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      double v = 0.0;
+#pragma unroll
+      for (int b = 0; b < 6; ++b) v += M[a][b] * ri[b];
+      z[size_t(a) * n_poses + t] = v;
+      rz += ri[a] * v;
+      rr += ri[a] * ri[a];
+    }
+  } else if (t - n_poses < n_edges) {
+    const uint32_t e = t - n_poses;
+    const double v = rs[e] / (h_s[e] * (1.0 + lambda));
+    zs[e] = v;
+    rz = rs[e] * v;
+    rr = rs[e] * rs[e];
+  }
+  __shared__ double lds[4][2];
+  const double a = wave_sum(rz), b = wave_sum(rr);
+  if ((threadIdx.x & 63) == 0) {
+    lds[threadIdx.x >> 6][0] = a;
+    lds[threadIdx.x >> 6][1] = b;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partials[2 * blockIdx.x] = (lds[0][0] + lds[1][0]) + (lds[2][0] + lds[3][0]);
+    partials[2 * blockIdx.x + 1] = (lds[0][1] + lds[1][1]) + (lds[2][1] + lds[3][1]);
+  }
+}
+
+// Generic vector helpers over the concatenated unknown vector (6 n_poses + n_edges entries).
+__global__ __launch_bounds__(256) void pgo_dot_kernel(const double* __restrict__ a, const double* __restrict__ b,
+                                                      size_t n, double* __restrict__ partials) {
+  double s = 0.0;
+  for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += size_t(gridDim.x) * 256) s += a[i] * b[i];
+  __shared__ double lds[4];
+  const double ws = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = ws;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+}
+
+// x += alpha p ; r -= alpha q
+__global__ __launch_bounds__(256) void pgo_cg_update_kernel(size_t n, double alpha, const double* __restrict__ p,
+                                                            const double* __restrict__ q, double* __restrict__ x,
+                                                            double* __restrict__ r) {
+  const size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= n) return;
+  x[i] += alpha * p[i];
+  r[i] -= alpha * q[i];
+}
+
+// p = z + beta p
+__global__ __launch_bounds__(256) void pgo_cg_direction_kernel(size_t n, double beta, const double* __restrict__ z,
+                                                               double* __restrict__ p) {
+  const size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= n) return;
+  p[i] = z[i] + beta * p[i];
+}
+
+// sums `count` block partials (stride `stride` doubles apart, `width` values each) in fixed order
+__global__ __launch_bounds__(256) void pgo_sum_partials_kernel(const double* __restrict__ partials, uint32_t count,
+                                                               int width, double* __restrict__ out) {
+  __shared__ double lds[256];
+  for (int w = 0; w < width; ++w) {
+    double s = 0.0;
+    for (uint32_t i = threadIdx.x; i < count; i += 256) s += partials[size_t(i) * width + w];
+    lds[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (int(threadIdx.x) < o) lds[threadIdx.x] += lds[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) out[w] = lds[0];
+    __syncthreads();
+  }
+}
+
+// poses <- poses [+] step ;  switches += step
+__global__ __launch_bounds__(256) void pgo_retract_kernel(uint32_t n_poses, uint32_t n_edges,
+                                                          const uint8_t* __restrict__ fixed,
+                                                          const uint8_t* __restrict__ sw_free,
+                                                          const double* __restrict__ dx, const double* __restrict__ dxs,
+                                                          double* p0, double* p1, double* p2, double* q0, double* q1,
+                                                          double* q2, double* q3, double* __restrict__ sw) {
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  if (t < n_poses) {
+    if (fixed[t]) return;
+    p0[t] += dx[t];
+    p1[t] += dx[size_t(1) * n_poses + t];
+    p2[t] += dx[size_t(2) * n_poses + t];
+    const double w[3] = {dx[size_t(3) * n_poses + t], dx[size_t(4) * n_poses + t], dx[size_t(5) * n_poses + t]};
+    const double theta = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    Quat4 d;
+    if (theta < 1e-6) {  // ComputeQuaternion, pose_graph_optimizer.h:70-86
+      d = {1.0, 0.5 * w[0], 0.5 * w[1], 0.5 * w[2]};
+    } else {
+      const double k = sin(0.5 * theta) / theta;
+      d = {cos(0.5 * theta), k * w[0], k * w[1], k * w[2]};
+    }
+    const Quat4 qn = qmul(Quat4{q0[t], q1[t], q2[t], q3[t]}, d);
+    const double inv = 1.0 / sqrt(qn.w * qn.w + qn.x * qn.x + qn.y * qn.y + qn.z * qn.z);
+    q0[t] = qn.w * inv;
+    q1[t] = qn.x * inv;
+    q2[t] = qn.y * inv;
+    q3[t] = qn.z * inv;
+  } else if (t - n_poses < n_edges) {
+    const uint32_t e = t - n_poses;
+    if (sw_free[e]) sw[e] += dxs[e];
+  }
+}
+
+}  // namespace nos

@@ -1,0 +1,103 @@
+"""Pose-graph optimisation handles over the C ABI (nos_pgo_*, include/nos.h) and a Python view of the
+C++ drop-in class PoseGraphOptimizerHip (csrc/host/nos_pgo_solver.hpp)."""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import c_double_p, check
+
+
+def _dp(a):
+    return a.ctypes.data_as(c_double_p)
+
+
+class PoseGraph:
+    """Device-resident pose graph (nos_pose_graph).  poses [n,7] = px py pz qw qx qy qz, meas [m,7] likewise."""
+
+    def __init__(self, ctx, poses, ref, qry, meas, switch_init=None, switch_free=None, fixed=None):
+        self._ctx = ctx
+        self._lib = ctx._lib
+        poses = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 7)
+        meas = np.ascontiguousarray(meas, dtype=np.float64).reshape(-1, 7)
+        ref = np.ascontiguousarray(ref, dtype=np.int32)
+        qry = np.ascontiguousarray(qry, dtype=np.int32)
+        self.n_poses, self.n_edges = poses.shape[0], ref.size
+        ip = ctypes.POINTER(ctypes.c_int32)
+        sw = None if switch_init is None else np.ascontiguousarray(switch_init, dtype=np.float64)
+        swf = None if switch_free is None else np.ascontiguousarray(switch_free, dtype=np.uint8).tobytes()
+        fx = None if fixed is None else np.ascontiguousarray(fixed, dtype=np.uint8).tobytes()
+        h = ctypes.c_void_p()
+        check(self._lib.nos_pgo_create(ctx.handle, self.n_poses, _dp(poses), self.n_edges, ref.ctypes.data_as(ip),
+                                       qry.ctypes.data_as(ip), _dp(meas), None if sw is None else _dp(sw), swf, fx,
+                                       ctypes.byref(h)), "nos_pgo_create")
+        self._h = h
+        ctx._adopt(self)
+
+    @property
+    def n_unknowns(self):
+        return int(self._lib.nos_pgo_num_unknowns(self._h))
+
+    def linearize(self):
+        """→ (cost, |gradient|)."""
+        c, g = ctypes.c_double(), ctypes.c_double()
+        check(self._lib.nos_pgo_linearize(self._h, ctypes.byref(c), ctypes.byref(g)), "nos_pgo_linearize")
+        return c.value, g.value
+
+    def solve(self, lam, max_iterations=500, rel_tolerance=1e-10):
+        """→ (pcg iterations, relative residual, |step|)."""
+        it, res, sn = ctypes.c_int(), ctypes.c_double(), ctypes.c_double()
+        check(self._lib.nos_pgo_solve(self._h, ctypes.c_double(lam), max_iterations, ctypes.c_double(rel_tolerance),
+                                      ctypes.byref(it), ctypes.byref(res), ctypes.byref(sn)), "nos_pgo_solve")
+        return it.value, res.value, sn.value
+
+    def retract(self):
+        check(self._lib.nos_pgo_retract(self._h), "nos_pgo_retract")
+
+    def state(self):
+        poses = np.zeros((self.n_poses, 7))
+        sw = np.zeros(max(self.n_edges, 1))
+        check(self._lib.nos_pgo_get_state(self._h, _dp(poses), _dp(sw)), "nos_pgo_get_state")
+        return poses, sw[:self.n_edges]
+
+    def vector(self, which):
+        """which: "gradient" | "step" | "hdiag"."""
+        idx = {"gradient": 0, "step": 1, "hdiag": 2}[which]
+        out = np.zeros(21 * self.n_poses if idx == 2 else self.n_unknowns)
+        check(self._lib.nos_pgo_get_vector(self._h, idx, _dp(out)), "nos_pgo_get_vector")
+        return out
+
+    def matvec(self, lam, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.zeros_like(x)
+        check(self._lib.nos_pgo_matvec(self._h, ctypes.c_double(lam), _dp(x), _dp(y)), "nos_pgo_matvec")
+        return y
+
+    def optimize(self, max_iterations=40, gradient_tolerance=1e-6, parameter_tolerance=1e-6, pcg_iterations=500,
+                 pcg_tolerance=1e-10):
+        """The reference's LM loop shape (always step; lambda x2 / x0.6 on the cost, clamp [1e-6, 1e-2]) driven
+        from Python — the C++ class PoseGraphOptimizerHip runs the same loop natively."""
+        lam, prev = 1e-3, np.finfo(np.float64).max
+        hist = []
+        it = 0
+        for it in range(max_iterations):
+            cost, gnorm = self.linearize()
+            pcg_it, res, step = self.solve(lam, pcg_iterations, pcg_tolerance)
+            self.retract()
+            hist.append((cost, gnorm, step, pcg_it, res))
+            if step < parameter_tolerance or gnorm < gradient_tolerance:
+                break
+            lam = min(max(lam * (2.0 if cost > prev else 0.6), 1e-6), 1e-2)
+            prev = cost
+        return it, hist
+
+    def close(self):
+        if self._h:
+            self._lib.nos_pgo_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
