@@ -19,6 +19,7 @@
 //   ReprojectionErrorMinimizer   REM/reprojection_error_minimizer.h:14-55
 //   MultiThreadExecutor          NO/multi_thread_executor.h (accepted, never used: the GPU
 //                                grid replaces the thread fan-out)
+//   Constraint, PoseParameter    NO/pose_graph_optimizer/types.h:11-19, pose_graph_optimizer.h:16-19
 #ifndef NOS_REFERENCE_API_HPP_
 #define NOS_REFERENCE_API_HPP_
 
@@ -271,6 +272,27 @@ class ReprojectionErrorMinimizer {
 };
 
 }  // namespace reprojection_error_minimizer
+
+namespace pose_graph_optimizer {
+
+// NO/pose_graph_optimizer/types.h:11-19
+enum class ConstraintType { kOdometry = 0, kLoop = 1 };
+
+struct Constraint {
+  int reference_pose_index{-1};
+  int query_pose_index{-1};
+  Pose relative_pose_from_reference_to_query{Pose::Identity()};
+  double switch_parameter{1.0};
+  ConstraintType type{ConstraintType::kOdometry};
+};
+
+// NO/pose_graph_optimizer/pose_graph_optimizer.h:16-19
+struct PoseParameter {
+  double position[3];
+  double orientation[4];  // w x y z
+};
+
+}  // namespace pose_graph_optimizer
 
 }  // namespace nonlinear_optimizer
 

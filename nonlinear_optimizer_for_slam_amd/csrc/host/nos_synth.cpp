@@ -244,6 +244,97 @@ int nos_synth_reproj(uint64_t seed, size_t n, double* const planes[5], int threa
   return 0;
 }
 
+// Synthetic pose graph of the BASELINE.json configs[4] shape: a smooth 3-D trajectory (0.5 m steps, small
+// random turns) with odometry constraints i -> i+1 and `extra_per_pose` loop constraints from every pose to
+// random poses 2..39 steps ahead; measurements = true relative pose + noise (1 cm / 5 mrad), initial
+// estimate = truth + noise (5 cm / 20 mrad), pose 0 exact.  poses [n][7] = px py pz qw qx qy qz.
+// ref / qry / meas must hold n - 1 + extra_per_pose * n entries; *n_edges receives the count written.
+int nos_synth_pose_graph(uint64_t seed, size_t n, int extra_per_pose, double* poses_true, double* poses_init,
+                         int32_t* ref, int32_t* qry, double* meas, size_t* n_edges) {
+  if (!poses_true || !poses_init || !ref || !qry || !meas || !n_edges || n < 2 || extra_per_pose < 0) return 1;
+  Rng rng(StreamSeed(seed, 7, 0));
+  auto qmul = [](const double* a, const double* b, double* o) {
+    o[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+    o[1] = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+    o[2] = a[0] * b[2] + a[2] * b[0] + a[3] * b[1] - a[1] * b[3];
+    o[3] = a[0] * b[3] + a[3] * b[0] + a[1] * b[2] - a[2] * b[1];
+  };
+  auto qexp = [](const double* w, double* o) {
+    const double th = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    const double k = th < 1e-9 ? 0.5 : std::sin(0.5 * th) / th;
+    o[0] = th < 1e-9 ? 1.0 : std::cos(0.5 * th);
+    o[1] = k * w[0];
+    o[2] = k * w[1];
+    o[3] = k * w[2];
+  };
+  auto qnorm = [](double* q) {
+    const double s = 1.0 / std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int k = 0; k < 4; ++k) q[k] *= s;
+  };
+  auto rot = [](const double* q, const double* v, double* o, bool transpose) {
+    const double w = q[0], x = q[1], y = q[2], z = q[3];
+    const double R[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - w * z),     2 * (x * z + w * y),
+                         2 * (x * y + w * z),     1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                         2 * (x * z - w * y),     2 * (y * z + w * x),     1 - 2 * (x * x + y * y)};
+    for (int i = 0; i < 3; ++i)
+      o[i] = transpose ? R[i] * v[0] + R[3 + i] * v[1] + R[6 + i] * v[2] : R[3 * i] * v[0] + R[3 * i + 1] * v[1] + R[3 * i + 2] * v[2];
+  };
+  double p[3] = {0, 0, 0}, q[4] = {1, 0, 0, 0};
+  for (size_t i = 0; i < n; ++i) {
+    double* t = poses_true + 7 * i;
+    for (int k = 0; k < 3; ++k) t[k] = p[k];
+    for (int k = 0; k < 4; ++k) t[3 + k] = q[k];
+    double w[3] = {0.05 * rng.Normal(), 0.05 * rng.Normal(), 0.05 * rng.Normal()}, dq[4], qn[4], step[3];
+    qexp(w, dq);
+    qmul(q, dq, qn);
+    qnorm(qn);
+    for (int k = 0; k < 4; ++k) q[k] = qn[k];
+    const double fwd[3] = {0.5, 0.0, 0.0};
+    rot(q, fwd, step, false);
+    for (int k = 0; k < 3; ++k) p[k] += step[k] + 0.02 * rng.Normal();
+  }
+  size_t m = 0;
+  auto add_edge = [&](size_t a, size_t b) {
+    const double* ta = poses_true + 7 * a;
+    const double* tb = poses_true + 7 * b;
+    double d[3] = {tb[0] - ta[0], tb[1] - ta[1], tb[2] - ta[2]}, tm[3];
+    rot(ta + 3, d, tm, true);
+    const double qa_conj[4] = {ta[3], -ta[4], -ta[5], -ta[6]};
+    double rel[4], nz[4], w[3] = {0.005 * rng.Normal(), 0.005 * rng.Normal(), 0.005 * rng.Normal()}, out[4];
+    qmul(qa_conj, tb + 3, rel);
+    qexp(w, nz);
+    qmul(rel, nz, out);
+    qnorm(out);
+    ref[m] = int32_t(a);
+    qry[m] = int32_t(b);
+    for (int k = 0; k < 3; ++k) meas[7 * m + k] = tm[k] + 0.01 * rng.Normal();
+    for (int k = 0; k < 4; ++k) meas[7 * m + 3 + k] = out[k];
+    ++m;
+  };
+  for (size_t i = 0; i + 1 < n; ++i) add_edge(i, i + 1);
+  for (size_t i = 0; i < n; ++i)
+    for (int k = 0; k < extra_per_pose; ++k) {
+      const size_t j = i + 2 + size_t(rng.Uniform() * 38.0);
+      if (j < n) add_edge(i, j);
+    }
+  for (size_t i = 0; i < n; ++i) {
+    const double* t = poses_true + 7 * i;
+    double* o = poses_init + 7 * i;
+    if (i == 0) {
+      for (int k = 0; k < 7; ++k) o[k] = t[k];
+      continue;
+    }
+    for (int k = 0; k < 3; ++k) o[k] = t[k] + 0.05 * rng.Normal();
+    double w[3] = {0.02 * rng.Normal(), 0.02 * rng.Normal(), 0.02 * rng.Normal()}, dq[4], qn[4];
+    qexp(w, dq);
+    qmul(t + 3, dq, qn);
+    qnorm(qn);
+    for (int k = 0; k < 4; ++k) o[3 + k] = qn[k];
+  }
+  *n_edges = m;
+  return 0;
+}
+
 // which: 0 = NDT scene, 1 = reprojection scene.  R row-major.
 void nos_synth_true_pose(int which, double R[9], double t[3]) {
   if (which == 0)

