@@ -31,21 +31,19 @@ namespace nos {
 
 constexpr double kSwitchPrior = 1e-9;  // ceres_cost_functor.h:93
 
+// Layout rule: data a lane GATHERS from another pose / constraint is stored as one 64-byte record (one cache
+// line per gather); data a lane reads for ITS OWN row is stored plane-wise (coalesced across the wave).
 struct PgoView {
-  // poses, SoA
-  const double* p[3];
-  const double* q[4];  // w x y z
-  // constraints, SoA
+  const double* pose;          // [n_poses][8]: px py pz qw qx qy qz pad  (64-byte records)
+  const double* edge;          // [n_edges][8]: t_m (3), q_m wxyz (4), switch value (1)
   const int32_t* ref;
   const int32_t* qry;
-  const double* tm[3];
-  const double* qm[4];
-  const double* sw;            // current switch value per constraint (1 for odometry)
   const uint8_t* sw_free;      // 1: the switch is an optimisation variable (loop constraints)
   // adjacency: constraints incident to pose i are adj[adj_off[i] .. adj_off[i+1]); entry = 2*edge + role
-  // (role 0: pose is the reference end, 1: the query end)
+  // (role 0: pose is the reference end, 1: the query end); adj_nbr holds the pose at the other end
   const uint32_t* adj_off;
   const uint32_t* adj;
+  const uint32_t* adj_nbr;
   const uint8_t* fixed;        // per pose
   uint32_t n_poses;
   uint32_t n_edges;
@@ -84,18 +82,34 @@ struct EdgeTerms {
   double C[9];   // -e_w I + [e_v]x                 (d r_R / d w_q)
 };
 
-__device__ __forceinline__ void edge_terms(const PgoView& G, uint32_t e, EdgeTerms& T) {
-  const int32_t ir = G.ref[e], iq = G.qry[e];
-  const Quat4 qr{G.q[0][ir], G.q[1][ir], G.q[2][ir], G.q[3][ir]};
-  const Quat4 qq{G.q[0][iq], G.q[1][iq], G.q[2][iq], G.q[3][iq]};
-  const Quat4 qm{G.qm[0][e], G.qm[1][e], G.qm[2][e], G.qm[3][e]};
-  const double tm[3] = {G.tm[0][e], G.tm[1][e], G.tm[2][e]};
+// 64-byte record load as four 16-byte loads
+__device__ __forceinline__ void load_record(const double* base, size_t index, double (&v)[8]) {
+  using V2 = double __attribute__((ext_vector_type(2)));
+  const V2* p = reinterpret_cast<const V2*>(base + 8 * index);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const V2 t = p[k];
+    v[2 * k] = t[0];
+    v[2 * k + 1] = t[1];
+  }
+}
+
+// Terms of constraint e given the records of its two ends (ir = reference pose, iq = query pose).
+__device__ __forceinline__ double edge_terms(const PgoView& G, uint32_t e, uint32_t ir, uint32_t iq, EdgeTerms& T) {
+  double pr[8], pq[8], ed[8];
+  load_record(G.pose, ir, pr);
+  load_record(G.pose, iq, pq);
+  load_record(G.edge, e, ed);
+  const Quat4 qr{pr[3], pr[4], pr[5], pr[6]};
+  const Quat4 qq{pq[3], pq[4], pq[5], pq[6]};
+  const Quat4 qm{ed[3], ed[4], ed[5], ed[6]};
+  const double tm[3] = {ed[0], ed[1], ed[2]};
   double Rr[9], Rm[9];
   qrot_matrix(qr, Rr);
   qrot_matrix(qm, Rm);
 #pragma unroll
   for (int i = 0; i < 3; ++i)
-    T.r[i] = (G.p[i][iq] - G.p[i][ir]) - (Rr[3 * i] * tm[0] + Rr[3 * i + 1] * tm[1] + Rr[3 * i + 2] * tm[2]);
+    T.r[i] = (pq[i] - pr[i]) - (Rr[3 * i] * tm[0] + Rr[3 * i + 1] * tm[1] + Rr[3 * i + 2] * tm[2]);
   const Quat4 qqc{qq.w, -qq.x, -qq.y, -qq.z};
   const Quat4 eq = qmul(qmul(qqc, qr), qm);
   T.r[3] = 2 * eq.x;
@@ -125,6 +139,7 @@ __device__ __forceinline__ void edge_terms(const PgoView& G, uint32_t e, EdgeTer
 #pragma unroll
     for (int j = 0; j < 3; ++j)
       T.B[3 * i + j] = Ep[3 * i] * Rm[3 * j] + Ep[3 * i + 1] * Rm[3 * j + 1] + Ep[3 * i + 2] * Rm[3 * j + 2];
+  return ed[7];  // current switch value
 }
 
 // y = J_role x  (6-vector) for the unscaled Jacobian of the given role.
@@ -164,7 +179,7 @@ __device__ __forceinline__ void add_JT(const EdgeTerms& T, int role, const doubl
 
 // Linearisation sweep.  Per pose: H_ii (21 upper, row-major) and g_i; per launch: the cost
 // (sum over constraints of |s r|^2 + (1-s)^2 c^2, counted at the reference end) as block partials.
-// hdiag: 21 planes of n_poses, grad: 6 planes of n_poses.
+// hdiag: 21 planes of n_poses (own-row data), grad: [n_poses][6] records.
 __global__ __launch_bounds__(256) void pgo_linearize_kernel(PgoView G, double* __restrict__ hdiag,
                                                             double* __restrict__ grad,
                                                             double* __restrict__ cost_partials) {
@@ -180,9 +195,9 @@ __global__ __launch_bounds__(256) void pgo_linearize_kernel(PgoView G, double* _
     for (uint32_t a = G.adj_off[i]; a < G.adj_off[i + 1]; ++a) {
       const uint32_t e = G.adj[a] >> 1;
       const int role = int(G.adj[a] & 1u);
+      const uint32_t j = G.adj_nbr[a];
       EdgeTerms T;
-      edge_terms(G, e, T);
-      const double s = G.sw[e];
+      const double s = edge_terms(G, e, role == 0 ? i : j, role == 0 ? j : i, T);
       if (role == 0) {
         double rr = 0.0;
 #pragma unroll
@@ -220,7 +235,7 @@ __global__ __launch_bounds__(256) void pgo_linearize_kernel(PgoView G, double* _
 #pragma unroll
     for (int k = 0; k < 21; ++k) hdiag[size_t(k) * G.n_poses + i] = H[k];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) grad[size_t(k) * G.n_poses + i] = g[k];
+    for (int k = 0; k < 6; ++k) grad[size_t(6) * i + k] = g[k];
   }
   // cost: block sum in fixed order
   __shared__ double lds[4];
@@ -241,45 +256,48 @@ __global__ __launch_bounds__(256) void pgo_switch_linearize_kernel(PgoView G, do
     return;
   }
   EdgeTerms T;
-  edge_terms(G, e, T);
+  const double s = edge_terms(G, e, uint32_t(G.ref[e]), uint32_t(G.qry[e]), T);
   double rr = 0.0;
 #pragma unroll
   for (int k = 0; k < 6; ++k) rr += T.r[k] * T.r[k];
-  const double s = G.sw[e];
   g_s[e] = s * rr - kSwitchPrior * kSwitchPrior * (1.0 - s);
   h_s[e] = rr + kSwitchPrior * kSwitchPrior;
 }
 
-// y = (H + lambda diag(H)) x for the pose rows, matrix free.  x / y: 6 planes of n_poses; xs: per-constraint
-// switch components (0 where the switch is not free).
+// y = (H + lambda diag(H)) x for the pose rows, matrix free, plus block partials of x.y (the p.Ap of CG).
+// x / y: [n_poses][6] records; xs: per-constraint switch components (0 where the switch is not free).
 __global__ __launch_bounds__(256) void pgo_matvec_pose_kernel(PgoView G, const double* __restrict__ hdiag,
                                                               double lambda, const double* __restrict__ x,
                                                               const double* __restrict__ xs,
-                                                              double* __restrict__ y) {
+                                                              double* __restrict__ y,
+                                                              double* __restrict__ dot_partials) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= G.n_poses) return;
   const size_t N = G.n_poses;
+  double xy = 0.0;
+  if (i < G.n_poses) {
   double xi[6], out[6];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) xi[k] = x[size_t(k) * N + i];
+  for (int k = 0; k < 6; ++k) xi[k] = x[size_t(6) * i + k];
   if (G.fixed[i]) {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) y[size_t(k) * N + i] = (1.0 + lambda) * xi[k];
-    return;
-  }
+    for (int k = 0; k < 6; ++k) {
+      out[k] = (1.0 + lambda) * xi[k];
+      y[size_t(6) * i + k] = out[k];
+      xy += xi[k] * out[k];
+    }
+  } else {
 #pragma unroll
   for (int k = 0; k < 6; ++k) out[k] = 0.0;
   for (uint32_t a = G.adj_off[i]; a < G.adj_off[i + 1]; ++a) {
     const uint32_t e = G.adj[a] >> 1;
     const int role = int(G.adj[a] & 1u);
-    const uint32_t j = uint32_t(role == 0 ? G.qry[e] : G.ref[e]);
+    const uint32_t j = G.adj_nbr[a];
     EdgeTerms T;
-    edge_terms(G, e, T);
-    const double s = G.sw[e];
+    const double s = edge_terms(G, e, role == 0 ? i : j, role == 0 ? j : i, T);
     double xj[6], v[6], vj[6];
     const bool jfixed = G.fixed[j] != 0;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) xj[k] = jfixed ? 0.0 : x[size_t(k) * N + j];
+    for (int k = 0; k < 6; ++k) xj[k] = jfixed ? 0.0 : x[size_t(6) * j + k];
     apply_J(T, role, xi, v);
     apply_J(T, 1 - role, xj, vj);
     const double xse = G.sw_free[e] ? xs[e] : 0.0;
@@ -289,37 +307,58 @@ __global__ __launch_bounds__(256) void pgo_matvec_pose_kernel(PgoView G, const d
   }
   const int dg[6] = {0, 6, 11, 15, 18, 20};
 #pragma unroll
-  for (int k = 0; k < 6; ++k) y[size_t(k) * N + i] = out[k] + lambda * hdiag[size_t(dg[k]) * N + i] * xi[k];
+  for (int k = 0; k < 6; ++k) {
+    const double v = out[k] + lambda * hdiag[size_t(dg[k]) * N + i] * xi[k];
+    y[size_t(6) * i + k] = v;
+    xy += xi[k] * v;
+  }
+  }
+  }
+  __shared__ double lds[4];
+  const double ws = wave_sum(xy);
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = ws;
+  __syncthreads();
+  if (threadIdx.x == 0) dot_partials[blockIdx.x] = (lds[0] + lds[1]) + (lds[2] + lds[3]);
 }
 
 // Switch rows of the same product.
+// Also emits block partials of xs.ys (appended after the pose blocks' partials by the caller).
 __global__ __launch_bounds__(256) void pgo_matvec_switch_kernel(PgoView G, const double* __restrict__ h_s, double lambda,
                                                                 const double* __restrict__ x,
                                                                 const double* __restrict__ xs,
-                                                                double* __restrict__ ys) {
+                                                                double* __restrict__ ys,
+                                                                double* __restrict__ dot_partials) {
   const uint32_t e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= G.n_edges) return;
-  if (!G.sw_free[e]) {
-    ys[e] = (1.0 + lambda) * xs[e];
-    return;
-  }
-  const size_t N = G.n_poses;
-  const uint32_t ir = uint32_t(G.ref[e]), iq = uint32_t(G.qry[e]);
-  EdgeTerms T;
-  edge_terms(G, e, T);
-  double xr[6], xq[6], vr[6], vq[6];
+  double xy = 0.0;
+  if (e < G.n_edges) {
+    double out;
+    if (!G.sw_free[e]) {
+      out = (1.0 + lambda) * xs[e];
+    } else {
+      const uint32_t ir = uint32_t(G.ref[e]), iq = uint32_t(G.qry[e]);
+      EdgeTerms T;
+      const double s = edge_terms(G, e, ir, iq, T);
+      double xr[6], xq[6], vr[6], vq[6];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    xr[k] = G.fixed[ir] ? 0.0 : x[size_t(k) * N + ir];
-    xq[k] = G.fixed[iq] ? 0.0 : x[size_t(k) * N + iq];
-  }
-  apply_J(T, 0, xr, vr);
-  apply_J(T, 1, xq, vq);
-  const double s = G.sw[e];
-  double acc = 0.0;
+      for (int k = 0; k < 6; ++k) {
+        xr[k] = G.fixed[ir] ? 0.0 : x[size_t(6) * ir + k];
+        xq[k] = G.fixed[iq] ? 0.0 : x[size_t(6) * iq + k];
+      }
+      apply_J(T, 0, xr, vr);
+      apply_J(T, 1, xq, vq);
+      double acc = 0.0;
 #pragma unroll
-  for (int k = 0; k < 6; ++k) acc += T.r[k] * (s * (vr[k] + vq[k]));
-  ys[e] = acc + h_s[e] * (1.0 + lambda) * xs[e];
+      for (int k = 0; k < 6; ++k) acc += T.r[k] * (s * (vr[k] + vq[k]));
+      out = acc + h_s[e] * (1.0 + lambda) * xs[e];
+    }
+    ys[e] = out;
+    xy = xs[e] * out;
+  }
+  __shared__ double lds[4];
+  const double ws = wave_sum(xy);
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = ws;
+  __syncthreads();
+  if (threadIdx.x == 0) dot_partials[blockIdx.x] = (lds[0] + lds[1]) + (lds[2] + lds[3]);
 }
 
 // Block-Jacobi preconditioner: inverse of the damped 6x6 diagonal block (Cholesky), stored as 21 upper
@@ -412,7 +451,7 @@ __global__ __launch_bounds__(256) void pgo_apply_precond_kernel(const double* __
     double ri[6], M[6][6];
     int k = 0;
 #pragma unroll
-    for (int a = 0; a < 6; ++a) ri[a] = r[size_t(a) * n_poses + t];
+    for (int a = 0; a < 6; ++a) ri[a] = r[size_t(6) * t + a];
 #pragma unroll
     for (int a = 0; a < 6; ++a)
 #pragma unroll
@@ -426,7 +465,7 @@ __global__ __launch_bounds__(256) void pgo_apply_precond_kernel(const double* __
       double v = 0.0;
 #pragma unroll
       for (int b = 0; b < 6; ++b) v += M[a][b] * ri[b];
-      z[size_t(a) * n_poses + t] = v;
+      z[size_t(6) * t + a] = v;
       rz += ri[a] * v;
       rr += ri[a] * ri[a];
     }
@@ -503,15 +542,16 @@ __global__ __launch_bounds__(256) void pgo_retract_kernel(uint32_t n_poses, uint
                                                           const uint8_t* __restrict__ fixed,
                                                           const uint8_t* __restrict__ sw_free,
                                                           const double* __restrict__ dx, const double* __restrict__ dxs,
-                                                          double* p0, double* p1, double* p2, double* q0, double* q1,
-                                                          double* q2, double* q3, double* __restrict__ sw) {
+                                                          double* __restrict__ pose, double* __restrict__ edge) {
   const uint32_t t = blockIdx.x * 256 + threadIdx.x;
   if (t < n_poses) {
     if (fixed[t]) return;
-    p0[t] += dx[t];
-    p1[t] += dx[size_t(1) * n_poses + t];
-    p2[t] += dx[size_t(2) * n_poses + t];
-    const double w[3] = {dx[size_t(3) * n_poses + t], dx[size_t(4) * n_poses + t], dx[size_t(5) * n_poses + t]};
+    double* P = pose + size_t(8) * t;
+    const double* d6 = dx + size_t(6) * t;
+    P[0] += d6[0];
+    P[1] += d6[1];
+    P[2] += d6[2];
+    const double w[3] = {d6[3], d6[4], d6[5]};
     const double theta = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
     Quat4 d;
     if (theta < 1e-6) {  // ComputeQuaternion, pose_graph_optimizer.h:70-86
@@ -520,15 +560,15 @@ __global__ __launch_bounds__(256) void pgo_retract_kernel(uint32_t n_poses, uint
       const double k = sin(0.5 * theta) / theta;
       d = {cos(0.5 * theta), k * w[0], k * w[1], k * w[2]};
     }
-    const Quat4 qn = qmul(Quat4{q0[t], q1[t], q2[t], q3[t]}, d);
+    const Quat4 qn = qmul(Quat4{P[3], P[4], P[5], P[6]}, d);
     const double inv = 1.0 / sqrt(qn.w * qn.w + qn.x * qn.x + qn.y * qn.y + qn.z * qn.z);
-    q0[t] = qn.w * inv;
-    q1[t] = qn.x * inv;
-    q2[t] = qn.y * inv;
-    q3[t] = qn.z * inv;
+    P[3] = qn.w * inv;
+    P[4] = qn.x * inv;
+    P[5] = qn.y * inv;
+    P[6] = qn.z * inv;
   } else if (t - n_poses < n_edges) {
     const uint32_t e = t - n_poses;
-    if (sw_free[e]) sw[e] += dxs[e];
+    if (sw_free[e]) edge[size_t(8) * e + 7] += dxs[e];
   }
 }
 
