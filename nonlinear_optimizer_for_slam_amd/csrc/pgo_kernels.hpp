@@ -519,16 +519,24 @@ __global__ __launch_bounds__(256) void pgo_cg_direction_kernel(size_t n, double 
   p[i] = z[i] + beta * p[i];
 }
 
-// sums `count` block partials (stride `stride` doubles apart, `width` values each) in fixed order
-__global__ __launch_bounds__(256) void pgo_sum_partials_kernel(const double* __restrict__ partials, uint32_t count,
-                                                               int width, double* __restrict__ out) {
-  __shared__ double lds[256];
+// sums `count` block partials (`width` interleaved values each) in a fixed order: 1024 lanes stride the
+// rows with four independent accumulators, then a fixed tree over the lanes
+__global__ __launch_bounds__(1024) void pgo_sum_partials_kernel(const double* __restrict__ partials, uint32_t count,
+                                                                int width, double* __restrict__ out) {
+  __shared__ double lds[1024];
   for (int w = 0; w < width; ++w) {
-    double s = 0.0;
-    for (uint32_t i = threadIdx.x; i < count; i += 256) s += partials[size_t(i) * width + w];
-    lds[threadIdx.x] = s;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    uint32_t i = threadIdx.x;
+    for (; i + 3 * 1024 < count; i += 4 * 1024) {
+      s0 += partials[size_t(i) * width + w];
+      s1 += partials[size_t(i + 1024) * width + w];
+      s2 += partials[size_t(i + 2 * 1024) * width + w];
+      s3 += partials[size_t(i + 3 * 1024) * width + w];
+    }
+    for (; i < count; i += 1024) s0 += partials[size_t(i) * width + w];
+    lds[threadIdx.x] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
+    for (int o = 512; o > 0; o >>= 1) {
       if (int(threadIdx.x) < o) lds[threadIdx.x] += lds[threadIdx.x + o];
       __syncthreads();
     }
