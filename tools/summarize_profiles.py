@@ -16,7 +16,12 @@ src = os.path.join(ROOT, "gpurun_out")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 
-stats = glob.glob(os.path.join(src, "prof_stats", "*", "*_kernel_stats.csv"))[0]
+def newest(pattern):
+    """gpurun merges new files into gpurun_out/ without deleting older runs' files: take the latest."""
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+
+stats = newest(os.path.join(src, "prof_stats", "*", "*_kernel_stats.csv"))
 shutil.copy(stats, os.path.join(dst, "%s_bench_kernel_stats.csv" % tag))
 bench = json.load(open(os.path.join(src, "prof_stats.json")))
 rows = list(csv.DictReader(open(stats)))
@@ -24,7 +29,7 @@ asm = [r for r in rows if "assemble_kernel" in r["Name"]][0]
 
 
 def counter(run, name):
-    f = glob.glob(os.path.join(src, run, "*", "*_counter_collection.csv"))[0]
+    f = newest(os.path.join(src, run, "*", "*_counter_collection.csv"))
     vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
             if "assemble_kernel" in r["Kernel_Name"] and r["Counter_Name"] == name]
     kn = [r["Kernel_Name"] for r in csv.DictReader(open(f)) if "assemble_kernel" in r["Kernel_Name"]][0]
