@@ -183,6 +183,28 @@ size_t nos_scan_size(const nos_scan* scan);
 int nos_ndt_match(nos_ndt_map* map, nos_scan* scan, const double R[9], const double t[3],
                   int max_neighbors, int dtype, nos_dataset** out_ds, size_t* n_matches);
 
+/* ---- voxel-indexed NDT datasets (additive; SURVEY.md §8d "voxel-indexed layout") ------
+ * The reference copies the full NDT into every correspondence (MDM/types.h:23-26, :336 of the
+ * test harness), hence the flat 120-byte layout.  When many points share a voxel the same sums
+ * can be formed from {point, voxel id(s)} plus a table of voxel records: 24 B + 4 B per slot
+ * instead of 120 B per correspondence; the table stays in L2 / Infinity Cache and the kernel
+ * becomes fp64-ALU bound.  Such a dataset is used with nos_ndt6_accumulate / nos_ndt3_accumulate
+ * (and their _async forms) exactly like a flat one and gives the same sums (to rounding: the
+ * summation order differs).  index_planes[k][i] = voxel id of point i's k-th correspondence, or
+ * -1 for none (n_slots = 1 or 2).  sort_by_voxel != 0 reorders the points by slot-0 voxel id on
+ * the device so that a wave's table reads hit a few cache lines (order does not affect the sums).
+ * nos_ndt_match_indexed is nos_ndt_match producing this form directly.
+ * Roofline accounting: nos_dataset_stream_bytes() = n * (3 * sizeof(elem) + 4 * n_slots); never
+ * compare it with the 120-byte figure of the flat layout. */
+int nos_ndt_indexed_dataset_create(nos_ctx* ctx, size_t n_points,
+                                   const double* const point_planes[3], int n_slots,
+                                   const int32_t* const index_planes[], size_t n_voxels,
+                                   const double* means_xyz, const double* sqrt_infos, int dtype,
+                                   int sort_by_voxel, nos_dataset** out_ds);
+int nos_ndt_match_indexed(nos_ndt_map* map, nos_scan* scan, const double R[9], const double t[3],
+                          int max_neighbors, int dtype, int sort_by_voxel, nos_dataset** out_ds,
+                          size_t* n_matches);
+
 /* ---- NDT map construction on the device --------------------
  * Replaces UpdateNdtMap of the reference's test harness
  * (MDM/tests/simple_optimization_test.cc:236-281): voxelise points_xyz ([n][3], map frame) at

@@ -6,12 +6,12 @@ reference's Solve()/Options surface).  This package only binds them; importing i
 a GPU, using it does — there is no CPU fallback.
 """
 from . import _lib
-from .api import Context, NdtDataset, ReprojDataset, make_loss
+from .api import Context, NdtDataset, NdtIndexedDataset, ReprojDataset, make_loss
 from .solvers import (MahalanobisDistanceMinimizerHip, MahalanobisDistanceMinimizerHip3DOF, Options, Pose,
                       ReprojectionErrorMinimizerHip)
 
 __all__ = [
-    "Context", "NdtDataset", "ReprojDataset", "make_loss", "Options", "Pose",
+    "Context", "NdtDataset", "NdtIndexedDataset", "ReprojDataset", "make_loss", "Options", "Pose",
     "MahalanobisDistanceMinimizerHip", "MahalanobisDistanceMinimizerHip3DOF",
     "ReprojectionErrorMinimizerHip",
 ]

@@ -457,6 +457,160 @@ __global__ __launch_bounds__(BLOCK, MINW) void assemble_kernel(TiledLayout L,
   if (fin.counter != nullptr) finish_in_last_block<kOut, BLOCK>(partials, fin);
 }
 
+// ---------------------------------------------------------------- voxel-indexed variant
+//
+// The reference's data model copies the whole NDT into every correspondence (MDM/types.h:23-26), which
+// is what the flat 120-byte layout above streams.  When many points share a voxel (10 M points over
+// 200 k voxels = 50 per voxel) the same sums can be formed from  point (3 values) + voxel id(s)  and a
+// table of voxel records {mean(3), sqrt-information(9), pad}: 24 B + 4 B·K per point instead of
+// 120 B·K, with the table (≈ 25 MB at 200 k voxels) served from L2 / Infinity Cache.  Points are
+// stored sorted by voxel id (done once at dataset creation), so the lanes of a wave hit a handful
+// of table records that stay in L1.  The kernel is then fp64-ALU bound, not HBM bound; it is reported
+// separately from the 120-byte roofline.
+struct IndexedLayout {
+  const void* points;      // 3 planes of n_padded (element type T)
+  const int32_t* index;    // K planes of n_padded voxel ids, -1 = no correspondence in that slot
+  const void* table;       // [n_voxels][16] of T: mean(3) sqrt_information(9, row-major) pad(4)
+  uint64_t n_padded;       // multiple of the kernel chunk; pads carry index -1
+};
+
+template <typename T>
+__device__ __forceinline__ void load_voxel_record(const T* table, int32_t v, T (&rec)[12]) {
+  const T* p = table + size_t(16) * size_t(v);
+  if constexpr (sizeof(T) == 8) {
+    using V2 = double __attribute__((ext_vector_type(2)));
+    const V2* q = reinterpret_cast<const V2*>(p);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const V2 t = q[k];
+      rec[2 * k] = t[0];
+      rec[2 * k + 1] = t[1];
+    }
+  } else {
+    using V4 = float __attribute__((ext_vector_type(4)));
+    const V4* q = reinterpret_cast<const V4*>(p);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const V4 t = q[k];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) rec[4 * k + m] = t[m];
+    }
+  }
+}
+
+// Problem = Ndt6Problem / Ndt3Problem (their item() takes the same 15 values).  K = voxel slots per point.
+// The kernel is latency / ALU bound, so it is software pipelined by hand: while chunk c is being evaluated
+// the voxel records of chunk c+1 (ids already in registers) and the points + ids of chunk c+2 are in flight.
+// One large workgroup per CU (768 or 1024 threads) keeps the in-launch reduction at 256 tickets.
+template <typename Problem, typename T, int K, int BLOCK, int MINW>
+__global__ __launch_bounds__(BLOCK, MINW) void assemble_indexed_kernel(IndexedLayout L, typename Problem::Params P,
+                                                                      uint32_t n_chunks,
+                                                                      double* __restrict__ partials,
+                                                                      FusedFinal fin) {
+  constexpr int kOut = Problem::kOut;
+  const T* __restrict__ pts = static_cast<const T*>(L.points);
+  const T* __restrict__ table = static_cast<const T*>(L.table);
+  T acc[kOut];
+#pragma unroll
+  for (int k = 0; k < kOut; ++k) acc[k] = T(0);
+
+  auto load_point = [&](uint32_t c, T (&p)[3], int32_t (&vid)[K]) {
+    if (c < n_chunks) {
+      const uint64_t i = uint64_t(c) * BLOCK + threadIdx.x;
+      p[0] = __builtin_nontemporal_load(pts + i);
+      p[1] = __builtin_nontemporal_load(pts + L.n_padded + i);
+      p[2] = __builtin_nontemporal_load(pts + 2 * L.n_padded + i);
+#pragma unroll
+      for (int k = 0; k < K; ++k) vid[k] = __builtin_nontemporal_load(L.index + uint64_t(k) * L.n_padded + i);
+    } else {
+      p[0] = p[1] = p[2] = T(0);
+#pragma unroll
+      for (int k = 0; k < K; ++k) vid[k] = -1;
+    }
+  };
+  auto load_records = [&](const int32_t (&vid)[K], T (&rec)[K][12]) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) load_voxel_record<T>(table, vid[k] < 0 ? 0 : vid[k], rec[k]);  // id 0 is always readable
+  };
+
+  T p_cur[3], p_nxt[3], p_far[3];
+  int32_t v_cur[K], v_nxt[K], v_far[K];
+  T rec_cur[K][12], rec_nxt[K][12];
+  uint32_t c = blockIdx.x;
+  load_point(c, p_cur, v_cur);
+  load_point(c + gridDim.x, p_nxt, v_nxt);
+  load_records(v_cur, rec_cur);
+  for (; c < n_chunks; c += gridDim.x) {
+    load_point(c + 2 * gridDim.x, p_far, v_far);  // stage 1 of chunk c+2
+    load_records(v_nxt, rec_nxt);                   // stage 2 of chunk c+1
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      if (v_cur[k] >= 0) {
+        T x[15];
+        x[0] = p_cur[0];
+        x[1] = p_cur[1];
+        x[2] = p_cur[2];
+#pragma unroll
+        for (int m = 0; m < 12; ++m) x[3 + m] = rec_cur[k][m];
+        Problem::item(x, P, true, acc);
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      p_cur[m] = p_nxt[m];
+      p_nxt[m] = p_far[m];
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      v_cur[k] = v_nxt[k];
+      v_nxt[k] = v_far[k];
+#pragma unroll
+      for (int m = 0; m < 12; ++m) rec_cur[k][m] = rec_nxt[k][m];
+    }
+  }
+  double dacc[kOut];
+#pragma unroll
+  for (int k = 0; k < kOut; ++k) dacc[k] = double(acc[k]);
+  block_reduce_store<kOut, BLOCK>(dacc, partials + size_t(blockIdx.x) * kOut, fin.write_through != 0);
+  if (fin.counter != nullptr) finish_in_last_block<kOut, BLOCK>(partials, fin);
+}
+
+// dst[j] = src[perm[j]] for planes of T / int32 (dataset creation: apply the voxel-sort permutation)
+template <typename SRC, typename DST>
+__global__ __launch_bounds__(256) void gather_plane_kernel(const SRC* __restrict__ src, const uint32_t* __restrict__ perm,
+                                                           uint64_t n, uint64_t n_padded, DST pad_value,
+                                                           DST* __restrict__ dst) {
+  const uint64_t j = uint64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (j >= n_padded) return;
+  dst[j] = j < n ? DST(src[perm ? perm[j] : j]) : pad_value;
+}
+
+// voxel table: [V][3] means + [V][9] sqrt-informations (double) → [V][16] records of T
+template <typename T>
+__global__ __launch_bounds__(256) void build_voxel_table_kernel(const double* __restrict__ means,
+                                                                const double* __restrict__ sqrt_infos, uint64_t n_voxels,
+                                                                T* __restrict__ table) {
+  const uint64_t t = uint64_t(blockIdx.x) * 256 + threadIdx.x;
+  const uint64_t v = t >> 4;
+  const int k = int(t & 15);
+  if (v >= n_voxels) return;
+  T val = T(0);
+  if (k < 3)
+    val = T(means[3 * v + k]);
+  else if (k < 12)
+    val = T(sqrt_infos[9 * v + (k - 3)]);
+  table[t] = val;
+}
+
+// sort keys for the voxel ordering: slot-0 voxel id, absent (-1) last
+__global__ __launch_bounds__(256) void index_sort_key_kernel(const int32_t* __restrict__ idx0, uint64_t n,
+                                                             uint32_t* __restrict__ keys, uint32_t* __restrict__ ids) {
+  const uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= n) return;
+  keys[i] = idx0[i] < 0 ? 0xFFFFFFFFu : uint32_t(idx0[i]);
+  ids[i] = uint32_t(i);
+}
+
 // Fixed-order sum of the block rows: thread (slice, col) adds rows slice, slice+S, …;
 // then the S slice sums are added in slice order.  One block, 1024 threads.
 template <int NOUT>

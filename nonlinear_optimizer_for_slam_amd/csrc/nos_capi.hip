@@ -80,7 +80,7 @@ RcclApi* Rccl() {
     if (r_ != ncclSuccess) return fail(NOS_ERR_HIP, "%s failed: %s", #expr, Rccl()->GetErrorString(r_)); \
   } while (0)
 
-enum DatasetKind { kKindNdt = 1, kKindReproj = 2 };
+enum DatasetKind { kKindNdt = 1, kKindReproj = 2, kKindNdtIndexed = 3 };
 
 constexpr int kMaxPartialRows = 8192;  // upper bound on grid size of the assemble kernel
 constexpr int kMaxOut = 28;
@@ -122,6 +122,11 @@ struct Shard {
   nos::TiledLayout layout{};
   void* data = nullptr;
   size_t bytes = 0;
+  // voxel-indexed datasets (kKindNdtIndexed): data = 3 point planes; plus
+  int32_t* index = nullptr;   // n_slots planes of n_padded voxel ids
+  void* table = nullptr;      // [n_voxels][16] voxel records
+  int n_slots = 0;
+  size_t n_voxels = 0;
 };
 
 }  // namespace
@@ -326,8 +331,12 @@ int launch_assemble(const nos_dataset* ds, const Shard& sh, const Request& rq, d
   return NOS_OK;
 }
 
+int launch_indexed(const nos_dataset* ds, const Shard& sh, const Request& rq, double* partials,
+                   const nos::FusedFinal& fin, hipStream_t stream, int* rows_out);
+
 int launch_assemble_raw(const nos_dataset* ds, const Shard& sh, const Request& rq, double* partials,
                         const nos::FusedFinal& fin, hipStream_t stream, int* rows_out) {
+  if (ds->kind == kKindNdtIndexed) return launch_indexed(ds, sh, rq, partials, fin, stream, rows_out);
   const nos_ctx* ctx = ds->ctx;
   const DeviceSlot& slot = ctx->slots[sh.slot];
   const bool nt = use_nontemporal(ds, sh);
@@ -406,7 +415,8 @@ int build_request(int problem, const nos_dataset* ds, const double* R, int nR, c
   if (!ds) return fail(NOS_ERR_INVALID_ARGUMENT, "dataset is NULL");
   if (!R || !t) return fail(NOS_ERR_INVALID_ARGUMENT, "pose pointer is NULL");
   const int want_kind = (problem == 2) ? kKindReproj : kKindNdt;
-  if (ds->kind != want_kind) return fail(NOS_ERR_WRONG_KIND, "dataset kind does not match the entry point");
+  if (ds->kind != want_kind && !(want_kind == kKindNdt && ds->kind == kKindNdtIndexed))
+    return fail(NOS_ERR_WRONG_KIND, "dataset kind does not match the entry point");
   memset(rq, 0, sizeof *rq);
   rq->problem = problem;
   for (int k = 0; k < nR; ++k) rq->R[k] = R[k];
@@ -967,10 +977,10 @@ int nos_reproj_dataset_create_from_records(nos_ctx* ctx, size_t n, const void* r
 int nos_dataset_destroy(nos_dataset* ds) {
   if (!ds) return NOS_OK;
   for (Shard& sh : ds->shards) {
-    if (sh.data) {
-      (void)hipSetDevice(ds->ctx->slots[sh.slot].device);
-      (void)hipFree(sh.data);
-    }
+    if (sh.data || sh.index || sh.table) (void)hipSetDevice(ds->ctx->slots[sh.slot].device);
+    if (sh.data) (void)hipFree(sh.data);
+    if (sh.index) (void)hipFree(sh.index);
+    if (sh.table) (void)hipFree(sh.table);
   }
   delete ds;
   return NOS_OK;
@@ -979,7 +989,10 @@ int nos_dataset_destroy(nos_dataset* ds) {
 size_t nos_dataset_size(const nos_dataset* ds) { return ds ? ds->n : 0; }
 int nos_dataset_dtype(const nos_dataset* ds) { return ds ? ds->dtype : -1; }
 size_t nos_dataset_stream_bytes(const nos_dataset* ds) {
-  return ds ? ds->n * size_t(ds->n_fields) * elem_size(ds->dtype) : 0;
+  if (!ds) return 0;
+  if (ds->kind == kKindNdtIndexed)  // point (3 values) + one 4-byte voxel id per slot; the voxel table is cache resident
+    return ds->n * (3 * elem_size(ds->dtype) + sizeof(int32_t) * size_t(ds->shards.empty() ? 0 : ds->shards[0].n_slots));
+  return ds->n * size_t(ds->n_fields) * elem_size(ds->dtype);
 }
 
 int nos_ndt6_accumulate(nos_dataset* ds, const double R[9], const double t[3], const nos_loss* loss,
@@ -1566,3 +1579,5 @@ int nos_ndt_map_build(nos_ctx* ctx, size_t n_points, const double* points_xyz, d
 }  // extern "C"
 
 #include "nos_pgo.inc"
+
+#include "nos_indexed.inc"
