@@ -355,3 +355,24 @@ def test_c_abi_argument_errors_are_reported_not_crashed(ctx):
     assert b"NULL" in lib.nos_last_error()
     ds.close()
     rp.close()
+
+
+def test_eighty_million_correspondences_on_one_gpu(ctx):
+    """Largest BASELINE.json size (configs[3]: 80 M correspondences) resident on ONE device as fp32 storage
+    (4.8 GB): additivity over a 3-way split, so the single-GPU strong-scaling baseline is known to be right."""
+    n = 80_000_000
+    loss = ("exponential", 1.0, 1.0)
+    total = np.zeros(28)
+    parts = []
+    whole_planes = []
+    for k, cnt in enumerate((30_000_000, 30_000_000, 20_000_000)):
+        planes = synth.ndt_planes(cnt, 200_000, first_block=k * 500)
+        ds = NdtDataset.from_planes(ctx, planes, "f32")
+        total += ds.accumulate6(R_TEST, T_TEST, loss)
+        ds.close()
+        whole_planes.append(planes)
+    whole = NdtDataset.from_planes(ctx, np.concatenate(whole_planes, axis=1), "f32")
+    del whole_planes
+    assert len(whole) == n and whole.stream_bytes == n * 60
+    helpers.assert_normal_equations_close(whole.accumulate6(R_TEST, T_TEST, loss), total, 6, 2e-5)
+    whole.close()
