@@ -420,7 +420,7 @@ __device__ __forceinline__ void finish_in_last_block(const double* partials, con
 // Grid-stride over chunks of BLOCK*ITEMS correspondences.  `n_chunks * BLOCK * ITEMS`
 // must equal L.n_padded and the tile size must be a multiple of BLOCK*ITEMS (checked on
 // the host before launch).
-template <typename Problem, typename T, int ITEMS, int BLOCK, int MINW, bool NT>
+template <typename Problem, typename T, int ITEMS, int BLOCK, int MINW, bool NT, bool PREFETCH = false>
 __global__ __launch_bounds__(BLOCK, MINW) void assemble_kernel(TiledLayout L,
                                                               typename Problem::Params P,
                                                               uint32_t n_chunks,
@@ -435,18 +435,57 @@ __global__ __launch_bounds__(BLOCK, MINW) void assemble_kernel(TiledLayout L,
 #pragma unroll
   for (int k = 0; k < kOut; ++k) acc[k] = T(0);
 
-  for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
-    const uint64_t i0 = uint64_t(c) * kChunk + uint64_t(threadIdx.x) * ITEMS;
-    const uint64_t off = (i0 >> L.tile_shift) * L.tile_stride + (i0 & L.tile_mask);
-    T x[kF][ITEMS];
+  auto chunk_offset = [&](uint32_t c, uint64_t& i0) {
+    i0 = uint64_t(c) * kChunk + uint64_t(threadIdx.x) * ITEMS;
+    return (i0 >> L.tile_shift) * L.tile_stride + (i0 & L.tile_mask);
+  };
+  if constexpr (PREFETCH) {
+    // software pipelined: the 15 loads of the NEXT chunk are issued before the current chunk is
+    // evaluated, so a wave always has a chunk in flight while it computes
+    T xa[kF][ITEMS];
+    uint32_t c = blockIdx.x;
+    uint64_t i0 = 0;
+    if (c < n_chunks) {
+      const uint64_t off = chunk_offset(c, i0);
 #pragma unroll
-    for (int f = 0; f < kF; ++f) load_items<T, ITEMS, NT>(base + off + uint64_t(f) * L.field_stride, x[f]);
+      for (int f = 0; f < kF; ++f) load_items<T, ITEMS, NT>(base + off + uint64_t(f) * L.field_stride, xa[f]);
+    }
+    for (; c < n_chunks; c += gridDim.x) {
+      T xb[kF][ITEMS];
+      uint64_t i1 = 0;
+      const uint32_t cn = c + gridDim.x;
+      if (cn < n_chunks) {
+        const uint64_t off = chunk_offset(cn, i1);
 #pragma unroll
-    for (int it = 0; it < ITEMS; ++it) {
-      T xi[kF];
+        for (int f = 0; f < kF; ++f) load_items<T, ITEMS, NT>(base + off + uint64_t(f) * L.field_stride, xb[f]);
+      }
 #pragma unroll
-      for (int f = 0; f < kF; ++f) xi[f] = x[f][it];
-      Problem::item(xi, P, (i0 + it) < L.n, acc);
+      for (int it = 0; it < ITEMS; ++it) {
+        T xi[kF];
+#pragma unroll
+        for (int f = 0; f < kF; ++f) xi[f] = xa[f][it];
+        Problem::item(xi, P, (i0 + it) < L.n, acc);
+      }
+#pragma unroll
+      for (int f = 0; f < kF; ++f)
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) xa[f][it] = xb[f][it];
+      i0 = i1;
+    }
+  } else {
+    for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+      uint64_t i0 = 0;
+      const uint64_t off = chunk_offset(c, i0);
+      T x[kF][ITEMS];
+#pragma unroll
+      for (int f = 0; f < kF; ++f) load_items<T, ITEMS, NT>(base + off + uint64_t(f) * L.field_stride, x[f]);
+#pragma unroll
+      for (int it = 0; it < ITEMS; ++it) {
+        T xi[kF];
+#pragma unroll
+        for (int f = 0; f < kF; ++f) xi[f] = x[f][it];
+        Problem::item(xi, P, (i0 + it) < L.n, acc);
+      }
     }
   }
 

@@ -185,9 +185,9 @@ size_t layout_elems(const nos::TiledLayout& L, int n_fields) { return L.n_padded
 
 // Number of compiled geometry variants per dtype (see the NOS_CASE tables below; index 0
 // is the default).
-constexpr int kNumVariants = 5;
+constexpr int kNumVariants = 7;
 
-template <typename Problem, typename T, int ITEMS, int BLOCK, int MINW>
+template <typename Problem, typename T, int ITEMS, int BLOCK, int MINW, bool PREFETCH = false>
 int launch_variant(const nos::TiledLayout& L, const typename Problem::Params& P, int grid_cap, int num_cus_hint,
                    bool nt, double* partials, const nos::FusedFinal& fin_in, hipStream_t stream, int* rows_out) {
   constexpr uint32_t kChunk = BLOCK * ITEMS;
@@ -204,10 +204,10 @@ int launch_variant(const nos::TiledLayout& L, const typename Problem::Params& P,
   // write-through hand-off only in the geometry it is documented valid for: at most one workgroup per CU
   fin.write_through = (fin.counter != nullptr && grid <= num_cus_hint && env_int("NOS_SC1", 1) != 0) ? 1 : 0;
   if (nt)
-    hipLaunchKernelGGL((nos::assemble_kernel<Problem, T, ITEMS, BLOCK, MINW, true>), dim3(grid), dim3(BLOCK), 0,
+    hipLaunchKernelGGL((nos::assemble_kernel<Problem, T, ITEMS, BLOCK, MINW, true, PREFETCH>), dim3(grid), dim3(BLOCK), 0,
                        stream, L, P, n_chunks, partials, fin);
   else
-    hipLaunchKernelGGL((nos::assemble_kernel<Problem, T, ITEMS, BLOCK, MINW, false>), dim3(grid), dim3(BLOCK), 0,
+    hipLaunchKernelGGL((nos::assemble_kernel<Problem, T, ITEMS, BLOCK, MINW, false, PREFETCH>), dim3(grid), dim3(BLOCK), 0,
                        stream, L, P, n_chunks, partials, fin);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(NOS_ERR_HIP, "assemble launch failed: %s", hipGetErrorString(e));
@@ -226,6 +226,12 @@ int launch_by_variant(int variant, int blocks_per_cu, int num_cus, const nos::Ti
     return launch_variant<Problem, T, ITEMS_, BLOCK_, MINW_>(L, P, bpc * num_cus, num_cus, nt, partials, fin, stream, \
                                                              rows_out);                             \
   }
+#define NOS_CASE_PF(idx, ITEMS_, BLOCK_, MINW_, BPC_)                                               \
+  case idx: {                                                                                       \
+    const int bpc = blocks_per_cu > 0 ? blocks_per_cu : BPC_;                                       \
+    return launch_variant<Problem, T, ITEMS_, BLOCK_, MINW_, true>(L, P, bpc * num_cus, num_cus, nt, partials, fin, \
+                                                                   stream, rows_out);               \
+  }
   if constexpr (sizeof(T) == 8) {
     switch (variant) {
       NOS_CASE(0, 1, 512, 3, 1)
@@ -233,6 +239,8 @@ int launch_by_variant(int variant, int blocks_per_cu, int num_cus, const nos::Ti
       NOS_CASE(2, 1, 256, 2, 2)
       NOS_CASE(3, 2, 256, 2, 2)
       NOS_CASE(4, 2, 512, 2, 1)
+      NOS_CASE_PF(5, 1, 512, 2, 1)
+      NOS_CASE_PF(6, 1, 256, 2, 2)
     }
   } else {
     switch (variant) {
@@ -241,9 +249,12 @@ int launch_by_variant(int variant, int blocks_per_cu, int num_cus, const nos::Ti
       NOS_CASE(2, 1, 256, 4, 2)
       NOS_CASE(3, 2, 256, 5, 2)
       NOS_CASE(4, 2, 256, 4, 2)
+      NOS_CASE_PF(5, 2, 512, 4, 1)
+      NOS_CASE_PF(6, 4, 512, 2, 1)
     }
   }
 #undef NOS_CASE
+#undef NOS_CASE_PF
   return fail(NOS_ERR_INVALID_ARGUMENT, "bad variant");
 }
 

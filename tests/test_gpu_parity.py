@@ -152,7 +152,7 @@ def test_every_launch_geometry_gives_the_same_sums(oracle):
     c = Context((0,))
     for dtype, rtol in (("f64", RTOL_F64), ("f32", RTOL_F32)):
         ds = NdtDataset.from_planes(c, planes, dtype)
-        for variant in range(5):
+        for variant in range(7):
             for bpc in (0, 1, 4):
                 c.set_launch(bpc, variant)
                 helpers.assert_normal_equations_close(ds.accumulate6(R_TEST, T_TEST, loss), want, 6, rtol)

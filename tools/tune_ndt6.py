@@ -27,8 +27,8 @@ for dtype in dtypes:
         gb = ds.stream_bytes / 1e9
         for nt in (0, 1):
             os.environ["NOS_NT"] = str(nt)
-            for variant in range(5):
-                for bpc in (0, 1, 2, 3, 4, 6, 8):
+            for variant in range(7):
+                for bpc in (0, 1, 2, 3, 4):
                     ctx.set_launch(bpc, variant)
                     try:
                         k, tot = ds.time_kernel6(R, t, loss, repeats=int(os.environ.get("TUNE_REPEATS", "10")))
