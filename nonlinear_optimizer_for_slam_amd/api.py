@@ -5,6 +5,7 @@ numpy arrays go in and out; torch is optional and only used for device-resident 
 device memory, streams and torch.distributed — all arithmetic happens in libnos_hip.so.
 """
 import ctypes
+import sys
 import weakref
 
 import numpy as np
@@ -125,6 +126,9 @@ class Context:
             self._h = None
 
     def __del__(self):
+        # at interpreter shutdown the HIP runtime may already be gone: leave the handle to the OS
+        if sys is None or sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:
@@ -204,6 +208,9 @@ class _Dataset:
             self._h = None
 
     def __del__(self):
+        # at interpreter shutdown the HIP runtime may already be gone: leave the handle to the OS
+        if sys is None or sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:
@@ -418,6 +425,9 @@ class NdtMap:
             self._h = None
 
     def __del__(self):
+        # at interpreter shutdown the HIP runtime may already be gone: leave the handle to the OS
+        if sys is None or sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:
@@ -445,6 +455,9 @@ class Scan:
             self._h = None
 
     def __del__(self):
+        # at interpreter shutdown the HIP runtime may already be gone: leave the handle to the OS
+        if sys is None or sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:

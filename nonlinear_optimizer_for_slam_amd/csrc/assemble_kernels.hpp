@@ -642,7 +642,7 @@ __global__ __launch_bounds__(256) void build_voxel_table_kernel(const double* __
 }
 
 // sort keys for the voxel ordering: slot-0 voxel id, absent (-1) last
-__global__ __launch_bounds__(256) void index_sort_key_kernel(const int32_t* __restrict__ idx0, uint64_t n,
+static __global__ __launch_bounds__(256) void index_sort_key_kernel(const int32_t* __restrict__ idx0, uint64_t n,
                                                              uint32_t* __restrict__ keys, uint32_t* __restrict__ ids) {
   const uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x;
   if (i >= n) return;

@@ -1,28 +1,15 @@
-// nos_capi.hip — host side of the C ABI declared in include/nos.h.
+// nos_core.hip — contexts, flat datasets, the accumulate entry points, RCCL hook (C ABI of include/nos.h).
 //
-// Owns contexts (per-device stream + workspaces), device-resident tiled-SoA datasets and
-// the launch logic around the kernels in assemble_kernels.hpp.  There is no CPU fallback:
-// without a usable HIP device every entry point fails with NOS_ERR_NO_DEVICE / NOS_ERR_HIP.
-#include <hip/hip_runtime.h>
-#include <dlfcn.h>
-#include <rccl/rccl.h>
+// Owns contexts (per-device stream + workspaces), device-resident tiled-SoA datasets and the launch logic around
+// the kernels in assemble_kernels.hpp.  There is no CPU fallback: without a usable HIP device every entry point
+// fails with NOS_ERR_NO_DEVICE / NOS_ERR_HIP.
+#include "nos_internal.hpp"
 
-#include <algorithm>
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <new>
-#include <string>
-#include <vector>
-
-#include "../../include/nos.h"
-#include "assemble_kernels.hpp"
+namespace nosd {
 
 namespace {
-
 thread_local std::string g_last_error;
+}
 
 int fail(int status, const char* fmt, ...) {
   char buf[512];
@@ -34,25 +21,7 @@ int fail(int status, const char* fmt, ...) {
   return status;
 }
 
-#define NOS_HIP_CHECK(expr)                                                               \
-  do {                                                                                    \
-    hipError_t e_ = (expr);                                                               \
-    if (e_ != hipSuccess)                                                                 \
-      return fail(e_ == hipErrorOutOfMemory ? NOS_ERR_OUT_OF_MEMORY : NOS_ERR_HIP,        \
-                  "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-  } while (0)
-
-// RCCL is bound at run time (dlopen) so that single-GPU use never needs it and so that a process
-// that already carries torch's copy of librccl shares that copy instead of loading a second one.
-struct RcclApi {
-  void* handle = nullptr;
-  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
-  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
-  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
-  const char* (*GetErrorString)(ncclResult_t) = nullptr;
-  bool ok = false;
-};
+const char* last_error_text() { return g_last_error.c_str(); }
 
 RcclApi* Rccl() {
   static RcclApi api;
@@ -74,74 +43,6 @@ RcclApi* Rccl() {
   return &api;
 }
 
-#define NOS_RCCL_CHECK(expr)                                                                     \
-  do {                                                                                           \
-    ncclResult_t r_ = (expr);                                                                    \
-    if (r_ != ncclSuccess) return fail(NOS_ERR_HIP, "%s failed: %s", #expr, Rccl()->GetErrorString(r_)); \
-  } while (0)
-
-enum DatasetKind { kKindNdt = 1, kKindReproj = 2, kKindNdtIndexed = 3 };
-
-constexpr int kMaxPartialRows = 8192;  // upper bound on grid size of the assemble kernel
-constexpr int kMaxOut = 28;
-
-struct DeviceSlot {
-  int device = 0;
-  int num_cus = 256;
-  hipStream_t own_stream = nullptr;
-  hipStream_t stream = nullptr;    // own_stream or an external one
-  double* partials = nullptr;      // [kMaxPartialRows][kMaxOut] device
-  double* d_out = nullptr;         // [kMaxOut] device
-  double* h_out = nullptr;         // pinned, device-mapped host block: [0..27] result, [32] sequence word
-  double* h_out_dev = nullptr;     // device-side address of h_out
-  unsigned int* counter = nullptr; // device ticket word of the in-launch final reduce (kept at 0 between launches)
-  unsigned long long seq = 0;      // last sequence value handed to a fused launch
-  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
-  // per-launch kernel timing (nos_ctx_profile_begin/_end): event pairs recorded on the
-  // launch stream around every assemble kernel while profiling is on
-  std::vector<hipEvent_t> prof_events;
-  size_t prof_used = 0;
-  bool prof_on = false;
-};
-
-}  // namespace
-
-struct nos_ctx {
-  std::vector<DeviceSlot> slots;
-  int blocks_per_cu = 0;  // 0 = default
-  int variant = 0;        // 0 = default; tuning knob (see pick_variant)
-  int tile_log2 = -1;     // -1 = default; 0 = planar
-  ncclComm_t comm = nullptr;  // set by nos_ctx_comm_init: accumulate results are summed over its ranks
-  int comm_ranks = 1;
-};
-
-namespace {
-
-struct Shard {
-  int slot = 0;
-  nos::TiledLayout layout{};
-  void* data = nullptr;
-  size_t bytes = 0;
-  // voxel-indexed datasets (kKindNdtIndexed): data = 3 point planes; plus
-  int32_t* index = nullptr;   // n_slots planes of n_padded voxel ids
-  void* table = nullptr;      // [n_voxels][16] voxel records
-  int n_slots = 0;
-  size_t n_voxels = 0;
-};
-
-}  // namespace
-
-struct nos_dataset {
-  nos_ctx* ctx = nullptr;
-  int kind = 0;
-  int dtype = NOS_F64;
-  int n_fields = 0;
-  size_t n = 0;
-  size_t tile = 0;
-  std::vector<Shard> shards;
-};
-
-namespace {
 
 constexpr size_t kDefaultTileLog2 = 10;  // 1024 correspondences per tile
 
@@ -250,7 +151,7 @@ int launch_by_variant(int variant, int blocks_per_cu, int num_cus, const nos::Ti
       NOS_CASE(3, 2, 256, 5, 2)
       NOS_CASE(4, 2, 256, 4, 2)
       NOS_CASE_PF(5, 2, 512, 4, 1)
-      NOS_CASE_PF(6, 4, 512, 2, 1)
+      NOS_CASE_PF(6, 4, 256, 2, 2)
     }
   }
 #undef NOS_CASE
@@ -276,21 +177,6 @@ int launch_by_loss(int loss_kind, int variant, int blocks_per_cu, int num_cus,
   return fail(NOS_ERR_INVALID_ARGUMENT, "unknown loss kind %d", loss_kind);
 }
 
-template <typename T>
-void fill_loss(const nos_loss* loss, T& la, T& lb, T& lc) {
-  la = lb = lc = T(0);
-  if (!loss) return;
-  if (loss->kind == NOS_LOSS_EXPONENTIAL) {
-    la = T(loss->a);
-    lb = T(loss->b);
-    lc = T(2.0 * loss->a * loss->b);
-  } else if (loss->kind == NOS_LOSS_HUBER) {
-    la = T(loss->a);
-    lb = T(loss->a * loss->a);
-    lc = T(2.0 * loss->a);
-  }
-}
-
 int check_loss(const nos_loss* loss, int* kind_out) {
   int kind = loss ? loss->kind : NOS_LOSS_NONE;
   if (kind < NOS_LOSS_NONE || kind > NOS_LOSS_HUBER) return fail(NOS_ERR_INVALID_ARGUMENT, "unknown loss kind %d", kind);
@@ -301,18 +187,6 @@ int check_loss(const nos_loss* loss, int* kind_out) {
   *kind_out = kind;
   return NOS_OK;
 }
-
-// What one accumulate call computes; POD so the same code path serves all three problems.
-struct Request {
-  int problem;  // 6, 3, 2 (reprojection)
-  double R[9];
-  double t[3];
-  double intr[4];
-  double min_depth;
-  nos_loss loss;
-  int loss_kind;
-  int n_out;
-};
 
 // Streaming (non-temporal) loads when the shard cannot stay resident in the 256 MiB
 // Infinity Cache between iterations; default-policy loads when it can.
@@ -341,9 +215,6 @@ int launch_assemble(const nos_dataset* ds, const Shard& sh, const Request& rq, d
   }
   return NOS_OK;
 }
-
-int launch_indexed(const nos_dataset* ds, const Shard& sh, const Request& rq, double* partials,
-                   const nos::FusedFinal& fin, hipStream_t stream, int* rows_out);
 
 int launch_assemble_raw(const nos_dataset* ds, const Shard& sh, const Request& rq, double* partials,
                         const nos::FusedFinal& fin, hipStream_t stream, int* rows_out) {
@@ -446,7 +317,6 @@ int build_request(int problem, const nos_dataset* ds, const double* R, int nR, c
   return NOS_OK;
 }
 
-constexpr int kSeqSlot = 32;  // index (in doubles) of the sequence word inside the pinned block
 
 // Device result → pinned host block + sequence word (used after an RCCL all-reduce, where the
 // in-launch final reduce cannot write to the host itself).
@@ -844,7 +714,20 @@ int create_from_records(nos_ctx* ctx, int kind, size_t n, const void* records, s
   return NOS_OK;
 }
 
-}  // namespace
+
+int zero_pad(int dtype, int n_fields, const nos::TiledLayout& L, void* dst, hipStream_t stream) {
+  return dtype == NOS_F64 ? zero_pad_launch<double>(n_fields, L, dst, stream) : zero_pad_launch<float>(n_fields, L, dst, stream);
+}
+
+int unpack_records(int dtype, const unsigned char* d_rec, size_t stride, const nos::FieldOffsets& fo, int n_fields,
+                   size_t first, size_t count, const nos::TiledLayout& L, void* dst, hipStream_t stream) {
+  return dtype == NOS_F64 ? unpack_launch<double>(d_rec, stride, fo, n_fields, first, count, L, dst, stream)
+                          : unpack_launch<float>(d_rec, stride, fo, n_fields, first, count, L, dst, stream);
+}
+
+}  // namespace nosd
+
+using namespace nosd;
 
 // ====================================================================== C ABI
 
@@ -1176,419 +1059,8 @@ const char* nos_status_string(int status) {
   return "unknown status";
 }
 
-const char* nos_last_error(void) { return g_last_error.c_str(); }
+const char* nos_last_error(void) { return nosd::last_error_text(); }
 const char* nos_version(void) { return "nos-hip 0.1 (gfx950)"; }
 
 }  // extern "C"
 
-// ====================================================================== matcher
-
-#include <map>
-
-#include "match_kernels.hpp"
-
-struct nos_ndt_map {
-  nos_ctx* ctx = nullptr;
-  size_t n_voxels = 0;  // valid voxels only
-  double* d_mean = nullptr;
-  double* d_sqrt_info = nullptr;
-  uint32_t* d_orig_id = nullptr;
-  uint64_t* d_cell_key = nullptr;
-  uint32_t* d_cell_start = nullptr;
-  uint32_t* d_cell_count = nullptr;
-  unsigned long long* d_n_matches = nullptr;
-  nos::MapView view{};
-};
-
-struct nos_scan {
-  nos_ctx* ctx = nullptr;
-  size_t n = 0;
-  double* d_planes = nullptr;  // [3][n]
-};
-
-namespace {
-
-template <typename T>
-hipError_t upload(T** dptr, const std::vector<T>& host) {
-  const size_t bytes = std::max<size_t>(host.size(), 1) * sizeof(T);
-  hipError_t e = hipMalloc(reinterpret_cast<void**>(dptr), bytes);
-  if (e == hipSuccess && !host.empty()) e = hipMemcpy(*dptr, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice);
-  return e;
-}
-
-}  // namespace
-
-extern "C" {
-
-int nos_ndt_map_create(nos_ctx* ctx, size_t n_voxels, const double* means_xyz, const double* sqrt_infos,
-                       const unsigned char* valid, double search_radius_sq, nos_ndt_map** out_map) {
-  if (!ctx || !out_map) return fail(NOS_ERR_INVALID_ARGUMENT, "ctx / out_map is NULL");
-  *out_map = nullptr;
-  if (ctx->slots.size() != 1) return fail(NOS_ERR_UNSUPPORTED, "the matcher needs a single-device context");
-  if ((!means_xyz || !sqrt_infos) && n_voxels > 0) return fail(NOS_ERR_INVALID_ARGUMENT, "map arrays are NULL");
-  if (!(search_radius_sq > 0.0) || !std::isfinite(search_radius_sq)) return fail(NOS_ERR_INVALID_ARGUMENT, "bad search radius");
-  if (n_voxels >= 0xFFFFFFFFull) return fail(NOS_ERR_UNSUPPORTED, "too many voxels");
-  const double cell = std::sqrt(search_radius_sq);
-  const double inv_cell = 1.0 / cell;
-  // bucket the valid voxels by grid cell (std::map keeps cells in key order → deterministic layout)
-  std::map<uint64_t, std::vector<uint32_t>> cells;
-  for (size_t v = 0; v < n_voxels; ++v) {
-    if (valid && !valid[v]) continue;  // `if (!ndt.is_valid) continue;` of the reference's matcher
-    const double* m = means_xyz + 3 * v;
-    if (!std::isfinite(m[0]) || !std::isfinite(m[1]) || !std::isfinite(m[2]))
-      return fail(NOS_ERR_INVALID_ARGUMENT, "voxel %zu has a non-finite mean", v);
-    const int64_t ix = int64_t(std::floor(m[0] * inv_cell)), iy = int64_t(std::floor(m[1] * inv_cell)),
-                  iz = int64_t(std::floor(m[2] * inv_cell));
-    const int64_t lim = (1 << 20) - 2;
-    if (std::llabs(ix) > lim || std::llabs(iy) > lim || std::llabs(iz) > lim)
-      return fail(NOS_ERR_UNSUPPORTED, "voxel %zu lies outside the addressable grid", v);
-    cells[nos::pack_cell(ix, iy, iz)].push_back(uint32_t(v));
-  }
-  size_t table_size = 16;
-  while (table_size < 2 * cells.size() + 1) table_size <<= 1;
-  std::vector<uint64_t> keys(table_size, nos::kEmptyCell);
-  std::vector<uint32_t> starts(table_size, 0), counts(table_size, 0), orig;
-  std::vector<double> mean_sorted, s_sorted;
-  for (const auto& kv : cells) {
-    uint32_t h = nos::hash_cell(kv.first) & uint32_t(table_size - 1);
-    while (keys[h] != nos::kEmptyCell) h = (h + 1) & uint32_t(table_size - 1);
-    keys[h] = kv.first;
-    starts[h] = uint32_t(orig.size());
-    counts[h] = uint32_t(kv.second.size());
-    for (uint32_t v : kv.second) {
-      orig.push_back(v);
-      for (int k = 0; k < 3; ++k) mean_sorted.push_back(means_xyz[3 * size_t(v) + k]);
-      for (int k = 0; k < 9; ++k) s_sorted.push_back(sqrt_infos[9 * size_t(v) + k]);
-    }
-  }
-  nos_ndt_map* map = new (std::nothrow) nos_ndt_map();
-  if (!map) return fail(NOS_ERR_OUT_OF_MEMORY, "host allocation failed");
-  map->ctx = ctx;
-  map->n_voxels = orig.size();
-  hipError_t e = hipSetDevice(ctx->slots[0].device);
-  if (e == hipSuccess) e = upload(&map->d_mean, mean_sorted);
-  if (e == hipSuccess) e = upload(&map->d_sqrt_info, s_sorted);
-  if (e == hipSuccess) e = upload(&map->d_orig_id, orig);
-  if (e == hipSuccess) e = upload(&map->d_cell_key, keys);
-  if (e == hipSuccess) e = upload(&map->d_cell_start, starts);
-  if (e == hipSuccess) e = upload(&map->d_cell_count, counts);
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&map->d_n_matches), sizeof(unsigned long long));
-  if (e != hipSuccess) {
-    nos_ndt_map_destroy(map);
-    return fail(e == hipErrorOutOfMemory ? NOS_ERR_OUT_OF_MEMORY : NOS_ERR_HIP, "map upload failed: %s", hipGetErrorString(e));
-  }
-  map->view.mean = map->d_mean;
-  map->view.sqrt_info = map->d_sqrt_info;
-  map->view.orig_id = map->d_orig_id;
-  map->view.cell_key = map->d_cell_key;
-  map->view.cell_start = map->d_cell_start;
-  map->view.cell_count = map->d_cell_count;
-  map->view.table_mask = uint32_t(table_size - 1);
-  map->view.inv_cell = inv_cell;
-  map->view.radius_sq = search_radius_sq;
-  *out_map = map;
-  return NOS_OK;
-}
-
-int nos_ndt_map_destroy(nos_ndt_map* map) {
-  if (!map) return NOS_OK;
-  (void)hipSetDevice(map->ctx->slots[0].device);
-  if (map->d_mean) (void)hipFree(map->d_mean);
-  if (map->d_sqrt_info) (void)hipFree(map->d_sqrt_info);
-  if (map->d_orig_id) (void)hipFree(map->d_orig_id);
-  if (map->d_cell_key) (void)hipFree(map->d_cell_key);
-  if (map->d_cell_start) (void)hipFree(map->d_cell_start);
-  if (map->d_cell_count) (void)hipFree(map->d_cell_count);
-  if (map->d_n_matches) (void)hipFree(map->d_n_matches);
-  delete map;
-  return NOS_OK;
-}
-
-size_t nos_ndt_map_size(const nos_ndt_map* map) { return map ? map->n_voxels : 0; }
-
-int nos_scan_create(nos_ctx* ctx, size_t n_points, const double* points_xyz, nos_scan** out_scan) {
-  if (!ctx || !out_scan) return fail(NOS_ERR_INVALID_ARGUMENT, "ctx / out_scan is NULL");
-  *out_scan = nullptr;
-  if (ctx->slots.size() != 1) return fail(NOS_ERR_UNSUPPORTED, "the matcher needs a single-device context");
-  if (!points_xyz && n_points > 0) return fail(NOS_ERR_INVALID_ARGUMENT, "points is NULL");
-  nos_scan* scan = new (std::nothrow) nos_scan();
-  if (!scan) return fail(NOS_ERR_OUT_OF_MEMORY, "host allocation failed");
-  scan->ctx = ctx;
-  scan->n = n_points;
-  DeviceSlot& slot = ctx->slots[0];
-  // [n][3] records (std::vector<Vec3>) → 3 planes, through the same record-unpack kernel as datasets
-  hipError_t e = hipSetDevice(slot.device);
-  void* staging = nullptr;
-  const size_t bytes = std::max<size_t>(n_points, 1) * 3 * sizeof(double);
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&scan->d_planes), bytes);
-  if (e == hipSuccess) e = hipMalloc(&staging, bytes);
-  int rc = NOS_OK;
-  if (e == hipSuccess && n_points > 0) {
-    e = hipMemcpyAsync(staging, points_xyz, n_points * 3 * sizeof(double), hipMemcpyHostToDevice, slot.stream);
-    nos::TiledLayout L{};
-    L.n = n_points;
-    L.n_padded = n_points;
-    L.tile_stride = 0;
-    L.field_stride = n_points;
-    L.tile_shift = 40;
-    L.tile_mask = 0xFFFFFFFFu;
-    nos::FieldOffsets fo{};
-    fo.off[0] = 0;
-    fo.off[1] = 8;
-    fo.off[2] = 16;
-    if (e == hipSuccess)
-      rc = unpack_launch<double>(static_cast<unsigned char*>(staging), 24, fo, 3, 0, n_points, L, scan->d_planes, slot.stream);
-    if (e == hipSuccess && rc == NOS_OK) e = hipStreamSynchronize(slot.stream);
-  }
-  if (staging) (void)hipFree(staging);
-  if (e != hipSuccess || rc != NOS_OK) {
-    nos_scan_destroy(scan);
-    if (rc != NOS_OK) return rc;
-    return fail(e == hipErrorOutOfMemory ? NOS_ERR_OUT_OF_MEMORY : NOS_ERR_HIP, "scan upload failed: %s", hipGetErrorString(e));
-  }
-  *out_scan = scan;
-  return NOS_OK;
-}
-
-int nos_scan_destroy(nos_scan* scan) {
-  if (!scan) return NOS_OK;
-  (void)hipSetDevice(scan->ctx->slots[0].device);
-  if (scan->d_planes) (void)hipFree(scan->d_planes);
-  delete scan;
-  return NOS_OK;
-}
-
-size_t nos_scan_size(const nos_scan* scan) { return scan ? scan->n : 0; }
-
-int nos_ndt_match(nos_ndt_map* map, nos_scan* scan, const double R[9], const double t[3], int max_neighbors,
-                  int dtype, nos_dataset** out_ds, size_t* n_matches) {
-  if (!map || !scan || !R || !t || !out_ds) return fail(NOS_ERR_INVALID_ARGUMENT, "NULL argument");
-  if (map->ctx != scan->ctx) return fail(NOS_ERR_INVALID_ARGUMENT, "map and scan belong to different contexts");
-  if (max_neighbors < 1 || max_neighbors > 2) return fail(NOS_ERR_UNSUPPORTED, "max_neighbors must be 1 or 2");
-  nos_ctx* ctx = map->ctx;
-  nos_dataset* ds = nullptr;
-  int rc = dataset_new(ctx, kKindNdt, 2 * scan->n, dtype, out_ds, &ds);
-  if (rc != NOS_OK) return rc;
-  Shard& sh = ds->shards[0];
-  DeviceSlot& slot = ctx->slots[0];
-  nos::PosePod pose;
-  for (int k = 0; k < 9; ++k) pose.R[k] = R[k];
-  for (int k = 0; k < 3; ++k) pose.t[k] = t[k];
-  hipError_t e = hipSetDevice(slot.device);
-  if (e == hipSuccess) e = hipMemsetAsync(map->d_n_matches, 0, sizeof(unsigned long long), slot.stream);
-  if (e == hipSuccess && scan->n > 0) {
-    const dim3 grid(unsigned((scan->n + 255) / 256));
-    const double* px = scan->d_planes;
-    const double* py = scan->d_planes + scan->n;
-    const double* pz = scan->d_planes + 2 * scan->n;
-    if (dtype == NOS_F64)
-      hipLaunchKernelGGL((nos::match_kernel<double>), grid, dim3(256), 0, slot.stream, map->view, px, py, pz,
-                         uint64_t(scan->n), pose, max_neighbors, sh.layout, static_cast<double*>(sh.data),
-                         map->d_n_matches);
-    else
-      hipLaunchKernelGGL((nos::match_kernel<float>), grid, dim3(256), 0, slot.stream, map->view, px, py, pz,
-                         uint64_t(scan->n), pose, max_neighbors, sh.layout, static_cast<float*>(sh.data),
-                         map->d_n_matches);
-    e = hipGetLastError();
-  }
-  if (e == hipSuccess)
-    rc = (dtype == NOS_F64) ? zero_pad_launch<double>(ds->n_fields, sh.layout, sh.data, slot.stream)
-                            : zero_pad_launch<float>(ds->n_fields, sh.layout, sh.data, slot.stream);
-  unsigned long long count = 0;
-  if (e == hipSuccess && rc == NOS_OK)
-    e = hipMemcpyAsync(&count, map->d_n_matches, sizeof count, hipMemcpyDeviceToHost, slot.stream);
-  if (e == hipSuccess && rc == NOS_OK) e = hipStreamSynchronize(slot.stream);
-  if (e != hipSuccess || rc != NOS_OK) {
-    nos_dataset_destroy(ds);
-    if (rc != NOS_OK) return rc;
-    return fail(NOS_ERR_HIP, "matching failed: %s", hipGetErrorString(e));
-  }
-  if (n_matches) *n_matches = size_t(count);
-  *out_ds = ds;
-  return NOS_OK;
-}
-
-int nos_dataset_download(nos_dataset* ds, double* const planes[]) {
-  if (!ds || !planes) return fail(NOS_ERR_INVALID_ARGUMENT, "NULL argument");
-  size_t begin = 0;
-  for (const Shard& sh : ds->shards) {
-    DeviceSlot& slot = ds->ctx->slots[sh.slot];
-    const size_t cnt = sh.layout.n;
-    if (cnt == 0) continue;
-    NOS_HIP_CHECK(hipSetDevice(slot.device));
-    double* tmp = nullptr;
-    NOS_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&tmp), cnt * size_t(ds->n_fields) * sizeof(double)));
-    const dim3 grid(unsigned((cnt + 255) / 256), unsigned(ds->n_fields));
-    if (ds->dtype == NOS_F64)
-      hipLaunchKernelGGL((nos::untile_kernel<double>), grid, dim3(256), 0, slot.stream,
-                         static_cast<const double*>(sh.data), ds->n_fields, sh.layout, tmp);
-    else
-      hipLaunchKernelGGL((nos::untile_kernel<float>), grid, dim3(256), 0, slot.stream,
-                         static_cast<const float*>(sh.data), ds->n_fields, sh.layout, tmp);
-    hipError_t e = hipGetLastError();
-    for (int f = 0; f < ds->n_fields && e == hipSuccess; ++f)
-      e = hipMemcpyAsync(planes[f] + begin, tmp + size_t(f) * cnt, cnt * sizeof(double), hipMemcpyDeviceToHost, slot.stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(slot.stream);
-    (void)hipFree(tmp);
-    if (e != hipSuccess) return fail(NOS_ERR_HIP, "dataset download failed: %s", hipGetErrorString(e));
-    begin += cnt;
-  }
-  return NOS_OK;
-}
-
-}  // extern "C"
-
-// ====================================================================== map build
-
-#include <memory>
-#include <rocprim/rocprim.hpp>
-
-#include "mapbuild_kernels.hpp"
-
-struct nos_map_stats {
-  std::vector<double> means;            // [V][3] voxel order = ascending packed (ix, iy, iz)
-  std::vector<double> sqrt_infos;       // [V][9]
-  std::vector<unsigned char> valid;     // [V]
-  std::vector<uint32_t> counts;         // [V]
-  std::vector<int64_t> cells;           // [V][3] integer voxel coordinates
-};
-
-namespace {
-
-struct DeviceBuffers {
-  std::vector<void*> ptrs;
-  ~DeviceBuffers() {
-    for (void* p : ptrs)
-      if (p) (void)hipFree(p);
-  }
-  template <typename T>
-  hipError_t alloc(T** out, size_t count) {
-    void* p = nullptr;
-    hipError_t e = hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T));
-    if (e == hipSuccess) ptrs.push_back(p);
-    *out = static_cast<T*>(p);
-    return e;
-  }
-};
-
-}  // namespace
-
-extern "C" {
-
-int nos_map_stats_destroy(nos_map_stats* stats) {
-  delete stats;
-  return NOS_OK;
-}
-
-size_t nos_map_stats_size(const nos_map_stats* stats) { return stats ? stats->counts.size() : 0; }
-
-int nos_map_stats_get(const nos_map_stats* stats, double* means_xyz, double* sqrt_infos, unsigned char* valid,
-                      uint32_t* counts, int64_t* cells_xyz) {
-  if (!stats) return fail(NOS_ERR_INVALID_ARGUMENT, "stats is NULL");
-  const size_t V = stats->counts.size();
-  if (means_xyz) memcpy(means_xyz, stats->means.data(), V * 3 * sizeof(double));
-  if (sqrt_infos) memcpy(sqrt_infos, stats->sqrt_infos.data(), V * 9 * sizeof(double));
-  if (valid) memcpy(valid, stats->valid.data(), V);
-  if (counts) memcpy(counts, stats->counts.data(), V * sizeof(uint32_t));
-  if (cells_xyz) memcpy(cells_xyz, stats->cells.data(), V * 3 * sizeof(int64_t));
-  return NOS_OK;
-}
-
-int nos_ndt_map_build(nos_ctx* ctx, size_t n_points, const double* points_xyz, double voxel_resolution,
-                      double search_radius_sq, int flags, nos_ndt_map** out_map, nos_map_stats** out_stats) {
-  if (!ctx || !out_map) return fail(NOS_ERR_INVALID_ARGUMENT, "ctx / out_map is NULL");
-  *out_map = nullptr;
-  if (out_stats) *out_stats = nullptr;
-  if (ctx->slots.size() != 1) return fail(NOS_ERR_UNSUPPORTED, "map build needs a single-device context");
-  if (!(voxel_resolution > 0.0) || !std::isfinite(voxel_resolution)) return fail(NOS_ERR_INVALID_ARGUMENT, "bad voxel resolution");
-  if (n_points >= 0xFFFFFFFFull) return fail(NOS_ERR_UNSUPPORTED, "too many points for one build");
-  nos_scan* scan = nullptr;
-  int rc = nos_scan_create(ctx, n_points, points_xyz, &scan);  // [n][3] → 3 planes on the device
-  if (rc != NOS_OK) return rc;
-  DeviceSlot& slot = ctx->slots[0];
-  hipStream_t st = slot.stream;
-  DeviceBuffers buf;
-  uint64_t *keys = nullptr, *keys_sorted = nullptr, *uniq = nullptr;
-  uint32_t *idx = nullptr, *idx_sorted = nullptr, *counts = nullptr, *offsets = nullptr, *n_runs = nullptr;
-  hipError_t e = hipSetDevice(slot.device);
-  const size_t n = n_points;
-  if (e == hipSuccess) e = buf.alloc(&keys, n);
-  if (e == hipSuccess) e = buf.alloc(&keys_sorted, n);
-  if (e == hipSuccess) e = buf.alloc(&idx, n);
-  if (e == hipSuccess) e = buf.alloc(&idx_sorted, n);
-  if (e == hipSuccess) e = buf.alloc(&uniq, n);
-  if (e == hipSuccess) e = buf.alloc(&counts, n);
-  if (e == hipSuccess) e = buf.alloc(&offsets, n);
-  if (e == hipSuccess) e = buf.alloc(&n_runs, 1);
-  const double* px = scan->d_planes;
-  const double* py = scan->d_planes + n;
-  const double* pz = scan->d_planes + 2 * n;
-  uint32_t V = 0;
-  if (e == hipSuccess && n > 0) {
-    hipLaunchKernelGGL(nos::voxel_key_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, st, px, py, pz, uint64_t(n),
-                       1.0 / voxel_resolution, keys, idx);
-    e = hipGetLastError();
-    size_t t1 = 0, t2 = 0, t3 = 0;
-    void* tmp = nullptr;
-    if (e == hipSuccess) e = rocprim::radix_sort_pairs(nullptr, t1, keys, keys_sorted, idx, idx_sorted, n, 0, 64, st);
-    if (e == hipSuccess) e = rocprim::run_length_encode(nullptr, t2, keys_sorted, n, uniq, counts, n_runs, st);
-    if (e == hipSuccess) e = rocprim::exclusive_scan(nullptr, t3, counts, offsets, 0u, n, rocprim::plus<uint32_t>(), st);
-    if (e == hipSuccess) e = hipMalloc(&tmp, std::max(std::max(t1, t2), std::max(t3, size_t(16))));
-    if (e == hipSuccess) buf.ptrs.push_back(tmp);
-    if (e == hipSuccess) e = rocprim::radix_sort_pairs(tmp, t1, keys, keys_sorted, idx, idx_sorted, n, 0, 64, st);
-    if (e == hipSuccess) e = rocprim::run_length_encode(tmp, t2, keys_sorted, n, uniq, counts, n_runs, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(&V, n_runs, sizeof V, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e == hipSuccess && V > 0) e = rocprim::exclusive_scan(tmp, t3, counts, offsets, 0u, size_t(V), rocprim::plus<uint32_t>(), st);
-  }
-  std::unique_ptr<nos_map_stats> stats(new (std::nothrow) nos_map_stats());
-  if (!stats) e = hipErrorOutOfMemory;
-  double *d_mean = nullptr, *d_S = nullptr;
-  unsigned char* d_valid = nullptr;
-  if (e == hipSuccess) e = buf.alloc(&d_mean, size_t(V) * 3);
-  if (e == hipSuccess) e = buf.alloc(&d_S, size_t(V) * 9);
-  if (e == hipSuccess) e = buf.alloc(&d_valid, size_t(V));
-  if (e == hipSuccess && V > 0) {
-    const nos::MapBuildParams prm{5, 0.01, 0.01, (flags & NOS_MAP_PROPER_SQRT_INFORMATION) ? 1 : 0};
-    const unsigned blocks = unsigned((size_t(V) * nos::kWave + 255) / 256);
-    hipLaunchKernelGGL(nos::voxel_stats_kernel, dim3(blocks), dim3(256), 0, st, px, py, pz, idx_sorted, offsets, counts, V,
-                       prm, d_mean, d_S, d_valid);
-    e = hipGetLastError();
-  }
-  std::vector<uint64_t> h_keys(V);
-  if (e == hipSuccess) {
-    stats->means.resize(size_t(V) * 3);
-    stats->sqrt_infos.resize(size_t(V) * 9);
-    stats->valid.resize(V);
-    stats->counts.resize(V);
-    stats->cells.resize(size_t(V) * 3);
-  }
-  if (e == hipSuccess && V > 0) {
-    e = hipMemcpyAsync(stats->means.data(), d_mean, size_t(V) * 3 * sizeof(double), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(stats->sqrt_infos.data(), d_S, size_t(V) * 9 * sizeof(double), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(stats->valid.data(), d_valid, V, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(stats->counts.data(), counts, size_t(V) * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(h_keys.data(), uniq, size_t(V) * sizeof(uint64_t), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-  }
-  nos_scan_destroy(scan);
-  if (e != hipSuccess)
-    return fail(e == hipErrorOutOfMemory ? NOS_ERR_OUT_OF_MEMORY : NOS_ERR_HIP, "map build failed: %s", hipGetErrorString(e));
-  const int64_t bias = int64_t(1) << 20;
-  for (uint32_t v = 0; v < V; ++v) {
-    stats->cells[3 * size_t(v) + 0] = int64_t((h_keys[v] >> 42) & 0x1FFFFFull) - bias;
-    stats->cells[3 * size_t(v) + 1] = int64_t((h_keys[v] >> 21) & 0x1FFFFFull) - bias;
-    stats->cells[3 * size_t(v) + 2] = int64_t(h_keys[v] & 0x1FFFFFull) - bias;
-  }
-  rc = nos_ndt_map_create(ctx, V, stats->means.data(), stats->sqrt_infos.data(), stats->valid.data(), search_radius_sq,
-                          out_map);
-  if (rc != NOS_OK) return rc;
-  if (out_stats) *out_stats = stats.release();
-  return NOS_OK;
-}
-
-}  // extern "C"
-
-#include "nos_pgo.inc"
-
-#include "nos_indexed.inc"

@@ -1,5 +1,9 @@
-// nos_indexed.inc — voxel-indexed NDT datasets (included at the end of nos_capi.hip).
-// Kernel: assemble_indexed_kernel in assemble_kernels.hpp.
+// nos_indexed.hip — voxel-indexed NDT datasets.  Kernel: assemble_indexed_kernel in assemble_kernels.hpp.
+#include "nos_internal.hpp"
+
+#include <rocprim/rocprim.hpp>
+
+using namespace nosd;
 
 namespace {
 
@@ -41,8 +45,10 @@ int launch_indexed_by_loss(int loss_kind, int n_slots, const nos::IndexedLayout&
   return fail(NOS_ERR_INVALID_ARGUMENT, "unknown loss kind %d", loss_kind);
 }
 
-int launch_indexed(const nos_dataset* ds, const Shard& sh, const Request& rq, double* partials,
-                   const nos::FusedFinal& fin, hipStream_t stream, int* rows_out) {
+}  // namespace
+
+int nosd::launch_indexed(const nos_dataset* ds, const Shard& sh, const Request& rq, double* partials,
+                         const nos::FusedFinal& fin, hipStream_t stream, int* rows_out) {
   const nos_ctx* ctx = ds->ctx;
   const DeviceSlot& slot = ctx->slots[sh.slot];
   nos::IndexedLayout L{};
@@ -86,6 +92,8 @@ int launch_indexed(const nos_dataset* ds, const Shard& sh, const Request& rq, do
   }
   return fail(NOS_ERR_WRONG_KIND, "voxel-indexed datasets serve the NDT entry points only");
 }
+
+namespace {
 
 // Builds the dataset from device-resident inputs: point planes [3][n] (double), index planes [K][n] (int32),
 // voxel arrays (double).  Sorts by slot-0 voxel id when asked.  All on the context's stream.

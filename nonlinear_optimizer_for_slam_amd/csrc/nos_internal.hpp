@@ -1,0 +1,205 @@
+// nos_internal.hpp — declarations shared by the translation units of libnos_hip.so (not part of the ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/nos.h"
+#include "assemble_kernels.hpp"
+#include "match_kernels.hpp"
+
+namespace nosd {
+
+// thread-local text of the last failure + status pass-through (defined in nos_core.hip)
+int fail(int status, const char* fmt, ...);
+
+#define NOS_HIP_CHECK(expr)                                                               \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess)                                                                 \
+      return ::nosd::fail(e_ == hipErrorOutOfMemory ? NOS_ERR_OUT_OF_MEMORY : NOS_ERR_HIP,        \
+                  "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+// RCCL is bound at run time (dlopen) so that single-GPU use never needs it and so that a process
+// that already carries torch's copy of librccl shares that copy instead of loading a second one.
+struct RcclApi {
+  void* handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  bool ok = false;
+};
+
+RcclApi* Rccl();
+
+#define NOS_RCCL_CHECK(expr)                                                                     \
+  do {                                                                                           \
+    ncclResult_t r_ = (expr);                                                                    \
+    if (r_ != ncclSuccess) return ::nosd::fail(NOS_ERR_HIP, "%s failed: %s", #expr, Rccl()->GetErrorString(r_)); \
+  } while (0)
+
+enum DatasetKind { kKindNdt = 1, kKindReproj = 2, kKindNdtIndexed = 3 };
+
+constexpr int kMaxPartialRows = 8192;  // upper bound on grid size of the assemble kernel
+constexpr int kMaxOut = 28;
+
+struct DeviceSlot {
+  int device = 0;
+  int num_cus = 256;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;    // own_stream or an external one
+  double* partials = nullptr;      // [kMaxPartialRows][kMaxOut] device
+  double* d_out = nullptr;         // [kMaxOut] device
+  double* h_out = nullptr;         // pinned, device-mapped host block: [0..27] result, [32] sequence word
+  double* h_out_dev = nullptr;     // device-side address of h_out
+  unsigned int* counter = nullptr; // device ticket word of the in-launch final reduce (kept at 0 between launches)
+  unsigned long long seq = 0;      // last sequence value handed to a fused launch
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+  // per-launch kernel timing (nos_ctx_profile_begin/_end): event pairs recorded on the
+  // launch stream around every assemble kernel while profiling is on
+  std::vector<hipEvent_t> prof_events;
+  size_t prof_used = 0;
+  bool prof_on = false;
+};
+
+
+}  // namespace nosd
+
+struct nos_ctx {
+  std::vector<nosd::DeviceSlot> slots;
+  int blocks_per_cu = 0;  // 0 = default
+  int variant = 0;        // 0 = default; tuning knob (see pick_variant)
+  int tile_log2 = -1;     // -1 = default; 0 = planar
+  ncclComm_t comm = nullptr;  // set by nos_ctx_comm_init: accumulate results are summed over its ranks
+  int comm_ranks = 1;
+};
+
+namespace nosd {
+
+struct Shard {
+  int slot = 0;
+  nos::TiledLayout layout{};
+  void* data = nullptr;
+  size_t bytes = 0;
+  // voxel-indexed datasets (kKindNdtIndexed): data = 3 point planes; plus
+  int32_t* index = nullptr;   // n_slots planes of n_padded voxel ids
+  void* table = nullptr;      // [n_voxels][16] voxel records
+  int n_slots = 0;
+  size_t n_voxels = 0;
+};
+
+}  // namespace nosd
+
+struct nos_dataset {
+  nos_ctx* ctx = nullptr;
+  int kind = 0;
+  int dtype = NOS_F64;
+  int n_fields = 0;
+  size_t n = 0;
+  size_t tile = 0;
+  std::vector<nosd::Shard> shards;
+};
+
+struct nos_ndt_map {
+  nos_ctx* ctx = nullptr;
+  size_t n_voxels = 0;  // valid voxels only
+  double* d_mean = nullptr;
+  double* d_sqrt_info = nullptr;
+  uint32_t* d_orig_id = nullptr;
+  uint64_t* d_cell_key = nullptr;
+  uint32_t* d_cell_start = nullptr;
+  uint32_t* d_cell_count = nullptr;
+  unsigned long long* d_n_matches = nullptr;
+  nos::MapView view{};
+};
+
+struct nos_scan {
+  nos_ctx* ctx = nullptr;
+  size_t n = 0;
+  double* d_planes = nullptr;  // [3][n]
+};
+
+namespace nosd {
+
+constexpr int kSeqSlot = 32;  // index (in doubles) of the sequence word inside the pinned block
+
+template <typename T>
+hipError_t upload(T** dptr, const std::vector<T>& host) {
+  const size_t bytes = std::max<size_t>(host.size(), 1) * sizeof(T);
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(dptr), bytes);
+  if (e == hipSuccess && !host.empty()) e = hipMemcpy(*dptr, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice);
+  return e;
+}
+
+struct DeviceBuffers {
+  std::vector<void*> ptrs;
+  ~DeviceBuffers() {
+    for (void* p : ptrs)
+      if (p) (void)hipFree(p);
+  }
+  template <typename T>
+  hipError_t alloc(T** out, size_t count) {
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T));
+    if (e == hipSuccess) ptrs.push_back(p);
+    *out = static_cast<T*>(p);
+    return e;
+  }
+};
+
+
+// What one accumulate call computes; POD so the same code path serves all three problems.
+struct Request {
+  int problem;  // 6, 3, 2 (reprojection)
+  double R[9];
+  double t[3];
+  double intr[4];
+  double min_depth;
+  nos_loss loss;
+  int loss_kind;
+  int n_out;
+};
+
+template <typename T>
+inline void fill_loss(const nos_loss* loss, T& la, T& lb, T& lc) {
+  la = lb = lc = T(0);
+  if (!loss) return;
+  if (loss->kind == NOS_LOSS_EXPONENTIAL) {
+    la = T(loss->a);
+    lb = T(loss->b);
+    lc = T(2.0 * loss->a * loss->b);
+  } else if (loss->kind == NOS_LOSS_HUBER) {
+    la = T(loss->a);
+    lb = T(loss->a * loss->a);
+    lc = T(2.0 * loss->a);
+  }
+}
+
+// nos_core.hip
+int env_int(const char* name, int dflt);
+size_t elem_size(int dtype);
+int dataset_new(nos_ctx* ctx, int kind, size_t n, int dtype, nos_dataset** out, nos_dataset** made);
+int zero_pad(int dtype, int n_fields, const nos::TiledLayout& L, void* dst, hipStream_t stream);
+int unpack_records(int dtype, const unsigned char* d_rec, size_t stride, const nos::FieldOffsets& fo, int n_fields,
+                   size_t first, size_t count, const nos::TiledLayout& L, void* dst, hipStream_t stream);
+// nos_indexed.hip
+int launch_indexed(const nos_dataset* ds, const Shard& sh, const Request& rq, double* partials,
+                   const nos::FusedFinal& fin, hipStream_t stream, int* rows_out);
+
+}  // namespace nosd

@@ -1,0 +1,133 @@
+// nos_mapbuild.hip — NDT map construction on the device.
+#include "nos_internal.hpp"
+
+#include <rocprim/rocprim.hpp>
+
+#include "mapbuild_kernels.hpp"
+
+using namespace nosd;
+
+struct nos_map_stats {
+  std::vector<double> means;            // [V][3] voxel order = ascending packed (ix, iy, iz)
+  std::vector<double> sqrt_infos;       // [V][9]
+  std::vector<unsigned char> valid;     // [V]
+  std::vector<uint32_t> counts;         // [V]
+  std::vector<int64_t> cells;           // [V][3] integer voxel coordinates
+};
+
+extern "C" {
+
+int nos_map_stats_destroy(nos_map_stats* stats) {
+  delete stats;
+  return NOS_OK;
+}
+
+size_t nos_map_stats_size(const nos_map_stats* stats) { return stats ? stats->counts.size() : 0; }
+
+int nos_map_stats_get(const nos_map_stats* stats, double* means_xyz, double* sqrt_infos, unsigned char* valid,
+                      uint32_t* counts, int64_t* cells_xyz) {
+  if (!stats) return fail(NOS_ERR_INVALID_ARGUMENT, "stats is NULL");
+  const size_t V = stats->counts.size();
+  if (means_xyz) memcpy(means_xyz, stats->means.data(), V * 3 * sizeof(double));
+  if (sqrt_infos) memcpy(sqrt_infos, stats->sqrt_infos.data(), V * 9 * sizeof(double));
+  if (valid) memcpy(valid, stats->valid.data(), V);
+  if (counts) memcpy(counts, stats->counts.data(), V * sizeof(uint32_t));
+  if (cells_xyz) memcpy(cells_xyz, stats->cells.data(), V * 3 * sizeof(int64_t));
+  return NOS_OK;
+}
+
+int nos_ndt_map_build(nos_ctx* ctx, size_t n_points, const double* points_xyz, double voxel_resolution,
+                      double search_radius_sq, int flags, nos_ndt_map** out_map, nos_map_stats** out_stats) {
+  if (!ctx || !out_map) return fail(NOS_ERR_INVALID_ARGUMENT, "ctx / out_map is NULL");
+  *out_map = nullptr;
+  if (out_stats) *out_stats = nullptr;
+  if (ctx->slots.size() != 1) return fail(NOS_ERR_UNSUPPORTED, "map build needs a single-device context");
+  if (!(voxel_resolution > 0.0) || !std::isfinite(voxel_resolution)) return fail(NOS_ERR_INVALID_ARGUMENT, "bad voxel resolution");
+  if (n_points >= 0xFFFFFFFFull) return fail(NOS_ERR_UNSUPPORTED, "too many points for one build");
+  nos_scan* scan = nullptr;
+  int rc = nos_scan_create(ctx, n_points, points_xyz, &scan);  // [n][3] → 3 planes on the device
+  if (rc != NOS_OK) return rc;
+  DeviceSlot& slot = ctx->slots[0];
+  hipStream_t st = slot.stream;
+  DeviceBuffers buf;
+  uint64_t *keys = nullptr, *keys_sorted = nullptr, *uniq = nullptr;
+  uint32_t *idx = nullptr, *idx_sorted = nullptr, *counts = nullptr, *offsets = nullptr, *n_runs = nullptr;
+  hipError_t e = hipSetDevice(slot.device);
+  const size_t n = n_points;
+  if (e == hipSuccess) e = buf.alloc(&keys, n);
+  if (e == hipSuccess) e = buf.alloc(&keys_sorted, n);
+  if (e == hipSuccess) e = buf.alloc(&idx, n);
+  if (e == hipSuccess) e = buf.alloc(&idx_sorted, n);
+  if (e == hipSuccess) e = buf.alloc(&uniq, n);
+  if (e == hipSuccess) e = buf.alloc(&counts, n);
+  if (e == hipSuccess) e = buf.alloc(&offsets, n);
+  if (e == hipSuccess) e = buf.alloc(&n_runs, 1);
+  const double* px = scan->d_planes;
+  const double* py = scan->d_planes + n;
+  const double* pz = scan->d_planes + 2 * n;
+  uint32_t V = 0;
+  if (e == hipSuccess && n > 0) {
+    hipLaunchKernelGGL(nos::voxel_key_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, st, px, py, pz, uint64_t(n),
+                       1.0 / voxel_resolution, keys, idx);
+    e = hipGetLastError();
+    size_t t1 = 0, t2 = 0, t3 = 0;
+    void* tmp = nullptr;
+    if (e == hipSuccess) e = rocprim::radix_sort_pairs(nullptr, t1, keys, keys_sorted, idx, idx_sorted, n, 0, 64, st);
+    if (e == hipSuccess) e = rocprim::run_length_encode(nullptr, t2, keys_sorted, n, uniq, counts, n_runs, st);
+    if (e == hipSuccess) e = rocprim::exclusive_scan(nullptr, t3, counts, offsets, 0u, n, rocprim::plus<uint32_t>(), st);
+    if (e == hipSuccess) e = hipMalloc(&tmp, std::max(std::max(t1, t2), std::max(t3, size_t(16))));
+    if (e == hipSuccess) buf.ptrs.push_back(tmp);
+    if (e == hipSuccess) e = rocprim::radix_sort_pairs(tmp, t1, keys, keys_sorted, idx, idx_sorted, n, 0, 64, st);
+    if (e == hipSuccess) e = rocprim::run_length_encode(tmp, t2, keys_sorted, n, uniq, counts, n_runs, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(&V, n_runs, sizeof V, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess && V > 0) e = rocprim::exclusive_scan(tmp, t3, counts, offsets, 0u, size_t(V), rocprim::plus<uint32_t>(), st);
+  }
+  std::unique_ptr<nos_map_stats> stats(new (std::nothrow) nos_map_stats());
+  if (!stats) e = hipErrorOutOfMemory;
+  double *d_mean = nullptr, *d_S = nullptr;
+  unsigned char* d_valid = nullptr;
+  if (e == hipSuccess) e = buf.alloc(&d_mean, size_t(V) * 3);
+  if (e == hipSuccess) e = buf.alloc(&d_S, size_t(V) * 9);
+  if (e == hipSuccess) e = buf.alloc(&d_valid, size_t(V));
+  if (e == hipSuccess && V > 0) {
+    const nos::MapBuildParams prm{5, 0.01, 0.01, (flags & NOS_MAP_PROPER_SQRT_INFORMATION) ? 1 : 0};
+    const unsigned blocks = unsigned((size_t(V) * nos::kWave + 255) / 256);
+    hipLaunchKernelGGL(nos::voxel_stats_kernel, dim3(blocks), dim3(256), 0, st, px, py, pz, idx_sorted, offsets, counts, V,
+                       prm, d_mean, d_S, d_valid);
+    e = hipGetLastError();
+  }
+  std::vector<uint64_t> h_keys(V);
+  if (e == hipSuccess) {
+    stats->means.resize(size_t(V) * 3);
+    stats->sqrt_infos.resize(size_t(V) * 9);
+    stats->valid.resize(V);
+    stats->counts.resize(V);
+    stats->cells.resize(size_t(V) * 3);
+  }
+  if (e == hipSuccess && V > 0) {
+    e = hipMemcpyAsync(stats->means.data(), d_mean, size_t(V) * 3 * sizeof(double), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(stats->sqrt_infos.data(), d_S, size_t(V) * 9 * sizeof(double), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(stats->valid.data(), d_valid, V, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(stats->counts.data(), counts, size_t(V) * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(h_keys.data(), uniq, size_t(V) * sizeof(uint64_t), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+  }
+  nos_scan_destroy(scan);
+  if (e != hipSuccess)
+    return fail(e == hipErrorOutOfMemory ? NOS_ERR_OUT_OF_MEMORY : NOS_ERR_HIP, "map build failed: %s", hipGetErrorString(e));
+  const int64_t bias = int64_t(1) << 20;
+  for (uint32_t v = 0; v < V; ++v) {
+    stats->cells[3 * size_t(v) + 0] = int64_t((h_keys[v] >> 42) & 0x1FFFFFull) - bias;
+    stats->cells[3 * size_t(v) + 1] = int64_t((h_keys[v] >> 21) & 0x1FFFFFull) - bias;
+    stats->cells[3 * size_t(v) + 2] = int64_t(h_keys[v] & 0x1FFFFFull) - bias;
+  }
+  rc = nos_ndt_map_create(ctx, V, stats->means.data(), stats->sqrt_infos.data(), stats->valid.data(), search_radius_sq,
+                          out_map);
+  if (rc != NOS_OK) return rc;
+  if (out_stats) *out_stats = stats.release();
+  return NOS_OK;
+}
+
+}  // extern "C"
+

@@ -1,7 +1,9 @@
-// nos_pgo.inc — host side of the pose-graph entry points (included at the end of nos_capi.hip; shares its
-// context / error helpers).  Kernels: pgo_kernels.hpp.
+// nos_pgo.hip — host side of the pose-graph entry points.  Kernels: pgo_kernels.hpp.
+#include "nos_internal.hpp"
 
 #include "pgo_kernels.hpp"
+
+using namespace nosd;
 
 struct nos_pose_graph {
   nos_ctx* ctx = nullptr;

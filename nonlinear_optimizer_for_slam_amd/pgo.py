@@ -1,6 +1,7 @@
 """Pose-graph optimisation handles over the C ABI (nos_pgo_*, include/nos.h) and a Python view of the
 C++ drop-in class PoseGraphOptimizerHip (csrc/host/nos_pgo_solver.hpp)."""
 import ctypes
+import sys
 
 import numpy as np
 
@@ -97,6 +98,9 @@ class PoseGraph:
             self._h = None
 
     def __del__(self):
+        # at interpreter shutdown the HIP runtime may already be gone: leave the handle to the OS
+        if sys is None or sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:

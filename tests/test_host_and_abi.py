@@ -172,3 +172,24 @@ def test_synthetic_generator_is_thread_count_independent_and_seeded():
 def test_reference_record_layout_is_304_bytes():
     # MDM/types.h:11-26: 24 B point + 280 B NDT; the stand-in keeps the same record size
     assert synth.host_lib().nos_host_sizeof_ndt_correspondence() == 304
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/nos.h is the drop-in boundary: it must compile as C99 (no C++ / torch types in signatures) and a C
+    program must link against libnos_hip.so using nothing but that header."""
+    import subprocess
+    src = tmp_path / "abi.c"
+    src.write_text(
+        '#include <stdio.h>\n#include "nos.h"\n'
+        "int main(void) {\n"
+        "  nos_ctx* ctx = 0; int dev = 0;\n"
+        "  int rc = nos_ctx_create(&dev, 1, &ctx);\n"
+        '  printf("%s|%d|%s\\n", nos_version(), rc, nos_status_string(rc));\n'
+        "  if (rc == NOS_OK) nos_ctx_destroy(ctx);\n"
+        "  return 0;\n}\n")
+    exe = tmp_path / "abi"
+    csrc = os.path.join(ROOT, "nonlinear_optimizer_for_slam_amd", "csrc")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           str(src), "-o", str(exe), "-L", csrc, "-lnos_hip", "-Wl,-rpath," + csrc])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120).stdout
+    assert "gfx950" in out and ("|0|ok" in out or "|2|no HIP device" in out), out
