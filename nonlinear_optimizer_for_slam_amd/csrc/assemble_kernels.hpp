@@ -375,7 +375,8 @@ __device__ __forceinline__ void block_reduce_store(const double (&acc)[NOUT], do
 // agent-scope release → asm vmcnt(0) → relaxed agent atomic ticket;  last block: ticket
 // value is the "poll", one lane agent-scope acquire → vmcnt(0) → barrier → plain loads.
 struct FusedFinal {
-  unsigned int* counter;           // device word, 0 before the launch; reset to 0 by the last block
+  unsigned int* counter;           // device words (top counter at [0], 8 group counters at [32 * (1 + g)]), all 0
+                                   // before the launch and reset to 0 by the blocks that complete them
   double* out_dev;                 // device result (may be null)
   double* out_host;                // host-mapped pinned result (may be null)
   unsigned long long* seq_host;    // host-mapped pinned sequence word (may be null)
@@ -402,8 +403,24 @@ __device__ __forceinline__ void finish_in_last_block(const double* partials, con
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    const unsigned int ticket = __hip_atomic_fetch_add(fin.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned int last = (ticket == gridDim.x - 1) ? 1u : 0u;
+    // Two-level ticket: one device-scope counter saturates at ≈ 88 arrivals/µs (guide, "dequeue" / "fanin"
+    // rows: 256 arrivals ≈ 2.9 µs), so blocks first arrive on one of 8 group counters (group = blockIdx mod 8,
+    // i.e. blocks that share an XCD under round-robin placement — used for speed only, any grouping is correct);
+    // the last arriver of a group resets it and arrives on the top counter; the last of those finishes.  Every
+    // block has released (or written through and drained) its row BEFORE its first arrival, the atomics execute
+    // in arrival order at the memory side and each later arrival is issued only after the earlier one returned
+    // (data dependence), so when the top ticket reads "last" every row is already out of the writers' L2s.
+    unsigned int last = 0u;
+    const unsigned int group = blockIdx.x & 7u;
+    const unsigned int group_size = (gridDim.x - group + 7u) >> 3;
+    const unsigned int n_groups = gridDim.x < 8u ? gridDim.x : 8u;
+    unsigned int* group_counter = fin.counter + 32u * (1u + group);  // 128 bytes apart
+    const unsigned int t1 = __hip_atomic_fetch_add(group_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t1 == group_size - 1u) {
+      __hip_atomic_store(group_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+      const unsigned int t2 = __hip_atomic_fetch_add(fin.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last = (t2 == n_groups - 1u) ? 1u : 0u;
+    }
     if (last && !wt) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -765,8 +765,8 @@ int nos_ctx_create(const int* device_ids, int n_devices, nos_ctx** out_ctx) {
     if (e == hipSuccess) e = hipHostMalloc(&s.h_out, sizeof(double) * 64, hipHostMallocMapped);
     if (e == hipSuccess) memset(s.h_out, 0, sizeof(double) * 64);
     if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&s.h_out_dev), s.h_out, 0);
-    if (e == hipSuccess) e = hipMalloc(&s.counter, 64);
-    if (e == hipSuccess) e = hipMemset(s.counter, 0, 64);
+    if (e == hipSuccess) e = hipMalloc(&s.counter, 2048);  // top ticket + 8 group tickets, 128 bytes apart
+    if (e == hipSuccess) e = hipMemset(s.counter, 0, 2048);
     if (e == hipSuccess) e = hipEventCreate(&s.ev0);
     if (e == hipSuccess) e = hipEventCreate(&s.ev1);
     if (e == hipSuccess) e = hipEventCreate(&s.ev2);
