@@ -376,3 +376,28 @@ def test_eighty_million_correspondences_on_one_gpu(ctx):
     assert len(whole) == n and whole.stream_bytes == n * 60
     helpers.assert_normal_equations_close(whole.accumulate6(R_TEST, T_TEST, loss), total, 6, 2e-5)
     whole.close()
+
+
+def test_cpp_class_multi_shard_and_fp32_solve_agree_with_single_shard():
+    """HipOptions.device_ids with the device listed twice (single-process fan-out inside Solve()) and dtype."""
+    planes = synth.ndt_planes(80_003, 4000)
+    loss = ("exponential", 1.0, 1.0)
+    ref = solvers.MahalanobisDistanceMinimizerHip()
+    ref.SetLossFunction(loss)
+    p0 = solvers.Pose()
+    assert ref.Solve(solvers.Options(), planes, p0)
+    two = solvers.MahalanobisDistanceMinimizerHip(device_ids=(0, 0))
+    two.SetLossFunction(loss)
+    two.SetMultiThreadExecutor(object())  # accepted, ignored
+    p1 = solvers.Pose()
+    assert two.Solve(solvers.Options(), planes, p1)
+    assert two.report.iterations == ref.report.iterations
+    dt, dq = helpers.pose_delta(p0.R, p0.t, p1.R, p1.t)
+    assert dt < 1e-10 and dq < 1e-10
+    f32 = solvers.MahalanobisDistanceMinimizerHip3DOF(dtype="f32")
+    f32.SetLossFunction(loss)
+    f64 = solvers.MahalanobisDistanceMinimizerHip3DOF()
+    f64.SetLossFunction(loss)
+    pa, pb = solvers.Pose(), solvers.Pose()
+    assert f32.Solve(solvers.Options(), planes, pa) and f64.Solve(solvers.Options(), planes, pb)
+    assert np.max(np.abs(pa.t - pb.t)) < 2e-4 and np.max(np.abs(pa.R - pb.R)) < 2e-4
