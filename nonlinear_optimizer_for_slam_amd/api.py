@@ -280,6 +280,7 @@ class NdtIndexedDataset(NdtDataset):
     """Voxel-indexed NDT correspondences: points [3,n] + voxel ids [K,n] (-1 = none) + a voxel table
     (means [V,3], sqrt-informations [V,3,3]).  Same accumulate6 / accumulate3 interface and the same sums as
     the flat NdtDataset, at 24 B + 4 B·K per point instead of 120 B per correspondence (include/nos.h)."""
+    _n_planes = 3  # what nos_dataset_download returns for this kind: the (voxel-sorted) point planes
 
     @classmethod
     def from_arrays(cls, ctx, points, index, means, sqrt_infos, dtype="f64", sort_by_voxel=True):

@@ -100,3 +100,18 @@ def test_indexed_full_size_matches_flat(ctx):
     ind = NdtIndexedDataset.from_arrays(ctx, planes[0:3], idx, means, S, "f64", True)
     helpers.assert_normal_equations_close(ind.accumulate6(R_TEST, T_TEST, loss), want, 6, 1e-11)
     ind.close()
+
+
+def test_indexed_empty_and_download(ctx):
+    from nonlinear_optimizer_for_slam_amd import NdtIndexedDataset, api
+    ds = NdtIndexedDataset.from_arrays(ctx, np.zeros((3, 0)), np.zeros((1, 0), dtype=np.int32), np.zeros((1, 3)),
+                                       np.eye(3)[None])
+    assert len(ds) == 0 and np.all(ds.accumulate6(np.eye(3), np.zeros(3), None) == 0.0)
+    ds.close()
+    pts = np.arange(30, dtype=np.float64).reshape(3, 10)
+    idx = np.array([[3, 1, 2, 0, 1, 3, 2, 0, -1, 1]], dtype=np.int32)
+    ds = NdtIndexedDataset.from_arrays(ctx, pts, idx, np.zeros((4, 3)), np.tile(np.eye(3), (4, 1, 1)), "f64", True)
+    got = api.download(ds)            # points come back in voxel-sorted order (ids 0,0,1,1,1,2,2,3,3,none)
+    order = np.argsort(np.where(idx[0] < 0, 1 << 30, idx[0]), kind="stable")
+    assert np.array_equal(got, pts[:, order])
+    ds.close()
