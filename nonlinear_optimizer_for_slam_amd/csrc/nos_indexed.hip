@@ -118,6 +118,10 @@ int indexed_from_device(nos_ctx* ctx, size_t n, const double* d_points, int n_sl
   const size_t n_padded = std::max<size_t>(((n + pad - 1) / pad) * pad, pad);
   sh.layout.n = n;
   sh.layout.n_padded = n_padded;
+  sh.layout.tile_stride = 0;  // the three point planes are plain planar (nos_dataset_download relies on this)
+  sh.layout.field_stride = n_padded;
+  sh.layout.tile_shift = 40;
+  sh.layout.tile_mask = 0xFFFFFFFFu;
   const size_t es = elem_size(dtype);
   sh.bytes = n_padded * (3 * es + sizeof(int32_t) * size_t(n_slots));
   DeviceSlot& slot = ctx->slots[0];
