@@ -60,7 +60,9 @@ def cpu_baseline(planes, seconds):
     n = planes.shape[1]
     R = np.eye(3)
     t = np.zeros(3)
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # a one-GPU box shares its host with other jobs: stay within a fair CPU share unless told otherwise
+    cores = max(1, min(avail, int(os.environ.get("NOS_BENCH_CPU_THREADS", "32"))))
     p32 = planes.astype(np.float32)
     oracle.avx_ndt6_accumulate(p32[:, :80_000], R, t, LOSS, threads=cores)  # warm the pool / pages
     passes, t0 = 0, time.perf_counter()
@@ -72,8 +74,8 @@ def cpu_baseline(planes, seconds):
             break
     avx = {"value": n * passes / el, "unit": "corr/s", "cores": cores, "kind": "port",
            "sample": "%d full passes over the same %d-correspondence workload, AVX2+FMA fp32 lanes "
-                     "(restates ..._analytic_simd_various.cc:1300-1447), %d threads, reference thread partition"
-                     % (passes, n, cores)}
+                     "(restates ..._analytic_simd_various.cc:1300-1447), %d threads of %d visible cores, reference "
+                     "thread partition" % (passes, n, cores, avail)}
     del p32
     ns = min(n, 4_000_000)
     sub = np.ascontiguousarray(planes[:, :ns])

@@ -15,6 +15,7 @@
 //   5 % outliers uniform over 640x480, T_true: t = (-0.1, 0.123, -0.5), Rz(0.1).
 // RNG: splitmix64-seeded xoshiro256**, one independent stream per block of 65536 items, so the
 // output does not depend on the number of worker threads.
+#include <algorithm>
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
@@ -185,7 +186,7 @@ int nos_synth_ndt_shard(uint64_t seed, size_t n, size_t n_voxels, size_t first_b
   if (!planes || n_voxels == 0) return 1;
   for (int k = 0; k < 15; ++k)
     if (!planes[k] && n > 0) return 1;
-  if (threads <= 0) threads = int(std::thread::hardware_concurrency());
+  if (threads <= 0) threads = int(std::min(32u, std::max(1u, std::thread::hardware_concurrency())));
   std::vector<Voxel> voxels;
   MakeVoxels(seed, n_voxels, &voxels);
   double Rt[9], tt[3];
@@ -214,7 +215,7 @@ int nos_synth_reproj(uint64_t seed, size_t n, double* const planes[5], int threa
   if (!planes) return 1;
   for (int k = 0; k < 5; ++k)
     if (!planes[k] && n > 0) return 1;
-  if (threads <= 0) threads = int(std::thread::hardware_concurrency());
+  if (threads <= 0) threads = int(std::min(32u, std::max(1u, std::thread::hardware_concurrency())));
   double Rt[9], tt[3];
   TruePoseReproj(Rt, tt);
   const double fx = 525.0, fy = 525.0, cx = 320.0, cy = 240.0;
