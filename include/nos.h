@@ -319,9 +319,10 @@ int nos_ndt3_time_kernel(nos_dataset* ds, const double R2[4], const double t2[2]
                          double* total_ms);
 /* Per-launch device timing inside a running loop: between _begin and _end every assemble
  * kernel launched through this context is bracketed by a HIP event pair recorded on the
- * stream it is launched on (up to max_launches launches per device).  _end synchronises
+ * stream it is launched on (every sample_every-th launch, up to max_launches timed launches per
+ * device; the two event records cost about a microsecond of host time each).  _end synchronises
  * and returns the number of timed launches and their mean / min / max duration. */
-int nos_ctx_profile_begin(nos_ctx* ctx, int max_launches);
+int nos_ctx_profile_begin(nos_ctx* ctx, int max_launches, int sample_every);
 int nos_ctx_profile_end(nos_ctx* ctx, int* n_launches, double* mean_ms, double* min_ms,
                         double* max_ms);
 const char* nos_status_string(int status);

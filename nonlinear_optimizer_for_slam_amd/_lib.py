@@ -84,7 +84,7 @@ def _declare(lib):
     lib.nos_ctx_comm_init.argtypes = [vp, i, i, ctypes.c_char_p]
     lib.nos_ctx_comm_size.argtypes = [vp]
     lib.nos_ctx_comm_allreduce.argtypes = [vp, dp, i]
-    lib.nos_ctx_profile_begin.argtypes = [vp, i]
+    lib.nos_ctx_profile_begin.argtypes = [vp, i, i]
     lib.nos_ctx_profile_end.argtypes = [vp, ctypes.POINTER(i), dp, dp, dp]
     lib.nos_ndt_dataset_create.argtypes = [vp, sz, ctypes.POINTER(dp), i, c_void_pp]
     lib.nos_reproj_dataset_create.argtypes = [vp, sz, ctypes.POINTER(dp), i, c_void_pp]

@@ -102,8 +102,8 @@ class Context:
         check(self._lib.nos_ctx_comm_allreduce(self._h, _dp(v), v.size), "nos_ctx_comm_allreduce")
         return v
 
-    def profile_begin(self, max_launches=4096):
-        check(self._lib.nos_ctx_profile_begin(self._h, max_launches), "nos_ctx_profile_begin")
+    def profile_begin(self, max_launches=4096, sample_every=1):
+        check(self._lib.nos_ctx_profile_begin(self._h, max_launches, sample_every), "nos_ctx_profile_begin")
 
     def profile_end(self):
         """→ (n_launches, mean_ms, min_ms, max_ms) of the assemble kernels launched since profile_begin."""

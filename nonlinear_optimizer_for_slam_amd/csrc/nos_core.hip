@@ -205,7 +205,8 @@ int launch_assemble_raw(const nos_dataset* ds, const Shard& sh, const Request& r
 int launch_assemble(const nos_dataset* ds, const Shard& sh, const Request& rq, double* partials,
                     const nos::FusedFinal& fin, hipStream_t stream, int* rows_out) {
   DeviceSlot& slot = ds->ctx->slots[sh.slot];
-  const bool prof = slot.prof_on && slot.prof_used + 2 <= slot.prof_events.size();
+  const bool prof = slot.prof_on && (slot.prof_launches++ % slot.prof_every) == 0 &&
+                    slot.prof_used + 2 <= slot.prof_events.size();
   if (prof) NOS_HIP_CHECK(hipEventRecord(slot.prof_events[slot.prof_used], stream));
   const int rc = launch_assemble_raw(ds, sh, rq, partials, fin, stream, rows_out);
   if (rc != NOS_OK) return rc;
@@ -1006,8 +1007,9 @@ int nos_ctx_comm_allreduce(nos_ctx* ctx, double* values, int count) {
   return NOS_OK;
 }
 
-int nos_ctx_profile_begin(nos_ctx* ctx, int max_launches) {
-  if (!ctx || max_launches < 1 || max_launches > (1 << 20)) return fail(NOS_ERR_INVALID_ARGUMENT, "bad profile request");
+int nos_ctx_profile_begin(nos_ctx* ctx, int max_launches, int sample_every) {
+  if (!ctx || max_launches < 1 || max_launches > (1 << 20) || sample_every < 1)
+    return fail(NOS_ERR_INVALID_ARGUMENT, "bad profile request");
   for (DeviceSlot& s : ctx->slots) {
     NOS_HIP_CHECK(hipSetDevice(s.device));
     while (s.prof_events.size() < size_t(max_launches) * 2) {
@@ -1016,6 +1018,8 @@ int nos_ctx_profile_begin(nos_ctx* ctx, int max_launches) {
       s.prof_events.push_back(e);
     }
     s.prof_used = 0;
+    s.prof_every = sample_every;
+    s.prof_launches = 0;
     s.prof_on = true;
   }
   return NOS_OK;

@@ -76,6 +76,8 @@ struct DeviceSlot {
   std::vector<hipEvent_t> prof_events;
   size_t prof_used = 0;
   bool prof_on = false;
+  int prof_every = 1;       // time every prof_every-th launch (event records cost ≈ 1 µs of host time each)
+  long prof_launches = 0;
 };
 
 
