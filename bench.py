@@ -114,13 +114,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    import torch
     from nonlinear_optimizer_for_slam_amd import (Context, NdtDataset, NdtIndexedDataset, _lib, distributed, solvers,
                                                   synth)
 
+    # torch is only the launcher-side plumbing for N > 1 (process group, barrier, max-over-ranks); the N = 1 path
+    # does not touch it, so the bench does not depend on torch's own view of the GPU.
+    torch = None
     dist = None
     force_dist = os.environ.get("NOS_BENCH_FORCE_DIST", "0") == "1"  # exercise the N>1 code path on one GPU
     if world > 1 or force_dist:
+        import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         if force_dist and world == 1:
@@ -132,8 +135,6 @@ def main():
             probe = torch.ones(1, device="cuda")
             dist.all_reduce(probe)  # creates torch's communicator (and its banner) now
             torch.cuda.synchronize()
-    else:
-        torch.cuda.set_device(local_rank)
 
     n_local = args.points
     blocks_per_rank = (n_local + 65535) // 65536
@@ -211,9 +212,9 @@ def main():
             pose_t, pose_R = pose.t, pose.R.reshape(-1)
 
     def fence():
-        torch.cuda.synchronize()
         ctx.synchronize()
         if dist is not None:
+            torch.cuda.synchronize()
             dist.barrier()
 
     if args.warmup > 0:

@@ -44,7 +44,7 @@ RcclApi* Rccl() {
 }
 
 
-constexpr size_t kDefaultTileLog2 = 10;  // 1024 correspondences per tile
+constexpr size_t kDefaultTileLog2 = 0;  // planar planes with a skew (measured best and robust across sizes); > 0 = tiled
 
 size_t elem_size(int dtype) { return dtype == NOS_F32 ? sizeof(float) : sizeof(double); }
 
@@ -65,7 +65,9 @@ nos::TiledLayout make_layout(size_t n, int n_fields, int tile_log2) {
     L.n_padded = ((n + pad - 1) / pad) * pad;
     if (L.n_padded == 0) L.n_padded = pad;
     L.tile_stride = 0;
-    L.field_stride = L.n_padded;
+    // planes are skewed against each other so that the 15 concurrent streams of a block never start at the same
+    // offset modulo a large power of two (n_padded itself often is one)
+    L.field_stride = L.n_padded + size_t(env_int("NOS_PLANE_SKEW", 1088));
     L.tile_shift = 40;
     L.tile_mask = 0xFFFFFFFFu;
   } else {
@@ -80,7 +82,9 @@ nos::TiledLayout make_layout(size_t n, int n_fields, int tile_log2) {
   return L;
 }
 
-size_t layout_elems(const nos::TiledLayout& L, int n_fields) { return L.n_padded * size_t(n_fields); }
+size_t layout_elems(const nos::TiledLayout& L, int n_fields) {
+  return (L.tile_stride == 0 ? L.field_stride : L.n_padded) * size_t(n_fields);
+}
 
 // ------------------------------------------------------------------ launch variants
 
