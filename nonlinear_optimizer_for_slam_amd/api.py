@@ -1,6 +1,8 @@
 """Thin Python handles over the C ABI (include/nos.h): Context, NdtDataset, ReprojDataset.
 
-numpy arrays go in and out; torch is optional and only used for device-resident planes
+numpy arrays go in and out; torch is optional (import it BEFORE creating the first Context if it is going to be
+used in the same process: torch bundles its own HIP runtime with the system runtime's soname, and the first one
+loaded serves the whole process) and only used for device-resident planes
 (`from_device_planes`) and for device-resident results (`*_async`), i.e. as plumbing for
 device memory, streams and torch.distributed — all arithmetic happens in libnos_hip.so.
 """

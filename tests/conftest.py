@@ -3,6 +3,14 @@ import sys
 
 import pytest
 
+# torch ships its own copy of the HIP runtime (same soname as the system one libnos_hip.so links to): whichever is
+# loaded first serves the whole process.  Load torch first so that tests which hand torch tensors / streams to the C ABI
+# share one runtime with it, independent of test selection order.
+try:  # pragma: no cover - environment dependent
+    import torch  # noqa: F401
+except Exception:  # torch is plumbing only; the suite runs without it
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
