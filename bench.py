@@ -46,6 +46,9 @@ def parse_args():
     ap.add_argument("--layout", default="flat", choices=["flat", "indexed"],
                     help="flat = the reference's data model (120 B/corr, the headline); indexed = additive "
                          "voxel-indexed layout (28 B/point fp64), reported separately")
+    ap.add_argument("--loop", default="device", choices=["device", "host"],
+                    help="device: LM loop resident on the GPU (nos_ndt6_solve, the product default); "
+                         "host: the loop on the host around nos_ndt6_accumulate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="time budget per CPU baseline leg")
     return ap.parse_args()
@@ -184,7 +187,16 @@ def main():
     pose_R = np.eye(3).reshape(-1).copy()
     rep = np.zeros(5)
 
-    if comm_mode != "torch.distributed":
+    if comm_mode != "torch.distributed" and args.loop == "device":
+        def iterate(k):
+            nonlocal pose_t, pose_R
+            # tolerances 0: no convergence exit, exactly k iterations execute
+            pose_R, pose_t, r = ds.solve6(pose_R, pose_t, LOSS, max_iterations=k, gradient_tolerance=0.0,
+                                          parameter_tolerance=0.0)
+            if not r["ok"] or r["iterations"] != k or r["launches"] != k:
+                raise RuntimeError("device LM loop failed: %r" % (r,))
+            rep[:4] = [r["iterations"], r["printed_cost"], r["last_cost"], r["final_lambda"]]
+    elif comm_mode != "torch.distributed":
         def iterate(k):
             ok = host.nos_host_ndt6_iterate(ds._h, ctypes.byref(loss), ctypes.c_int(k),
                                             pose_t.ctypes.data_as(_lib.c_double_p),
@@ -220,8 +232,13 @@ def main():
     if args.warmup > 0:
         iterate(args.warmup)
     fence()
+    # Kernel duration for the roofline, from HIP events on the launch stream over the timed region.  Device-resident
+    # loop at N = 1: the launches form one back-to-back train, so ONE event pair brackets the whole train (an event
+    # between two queued kernels would serialise their dispatch) and the duration per launch is train / launches — an
+    # upper bound of the kernel's own duration.  Host loop / N > 1: an event pair around every 4th assemble launch.
+    bracket = comm_mode == "none" and args.loop == "device"
     if os.environ.get("NOS_BENCH_NO_EVENTS", "0") != "1":
-        ctx.profile_begin(args.steps + 8, sample_every=4)  # every 4th launch: keeps the probe's cost < 0.3 % of a step
+        ctx.profile_begin(args.steps + 8, sample_every=0 if bracket else 4)
     t0 = time.perf_counter()
     iterate(args.steps)
     fence()
@@ -261,8 +278,13 @@ def main():
             "points_per_gpu": n_local, "total_points": n_total, "voxels": N_VOXELS,
             "loss": "ExponentialLossFunction(1,1)", "parallelism": "corr-shard x%d, all-reduce 28 f64" % world,
             "collective": comm_mode,
-            "step": "LM iteration: assemble kernel + final reduce%s + 224 B readback + host 6x6 LDLT/pose update"
-                    % (" + RCCL all-reduce(28 f64)" if world > 1 else ""),
+            "loop": args.loop if comm_mode != "torch.distributed" else "host",
+            "step": ("LM iteration, device resident: assemble kernel + in-launch final reduce%s + 6x6 LDLT / pose update "
+                     "/ lambda schedule on the GPU, next launch already queued"
+                     % (" + RCCL all-reduce(28 f64) + step kernel" if world > 1 else ""))
+                    if (args.loop == "device" and comm_mode != "torch.distributed") else
+                    ("LM iteration: assemble kernel + final reduce%s + 224 B readback + host 6x6 LDLT/pose update"
+                     % (" + RCCL all-reduce(28 f64)" if world > 1 else "")),
         },
         "scalar_residuals_per_sec": 3.0 * value,
         "gn_iters_per_sec": args.steps / elapsed,
@@ -276,7 +298,10 @@ def main():
             "launches_timed": n_timed, "algorithmic_bytes_per_launch": bytes_per_launch,
             "bytes_per_corr": bytes_per_launch / max(n_local, 1),
             "frac_of_measured_copy_6290": achieved / HBM_MEASURED_COPY_GBPS,
-            "timing": "hipEvent pairs on the launch stream around every 4th assemble launch of the timed steps",
+            "timing": ("one hipEvent pair on the launch stream bracketing the back-to-back train of the timed steps' "
+                       "launches; duration per launch = train / launches (upper bound: includes the in-launch reduce, "
+                       "the LM step and any gap)") if bracket else
+                      "hipEvent pairs on the launch stream around every 4th assemble launch of the timed steps",
         },
     }
     # HBM traffic per launch comes from rocprofv3 PMC passes of this same command (they cannot be

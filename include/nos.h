@@ -268,6 +268,46 @@ int nos_reproj_accumulate_async(nos_dataset* ds, const double R[9], const double
                                 const double intr[4], const nos_loss* loss, double min_depth,
                                 double* d_out28);
 
+/* ---- the whole Levenberg-Marquardt loop, device resident ---------------------------------
+ * nos_ndt6_solve / nos_ndt3_solve / nos_reproj_solve replace the body of the reference's Solve():
+ *   MDM/..._analytic_simd.cc:30-108 (= ..._analytic.cc:57-157), MDM/..._analytic_3dof.cc:17-108,
+ *   REM/reprojection_error_minimizer_analytic.cc:15-105
+ * i.e. per iteration: ComputeCostAndDerivatives, H_kk *= 1 + lambda, ldlt().solve(-g), right-multiplicative
+ * pose update, the two convergence tests after the update, lambda *= 2 / 0.6 clamped to [1e-6, 1e-2].
+ * The loop state stays in device memory: the workgroup that completes the sums of a launch runs that
+ * loop body and leaves the new pose for the next launch, so consecutive iterations run back-to-back on
+ * the GPU with no host step in between (the host keeps `launches_in_flight` launches queued and reads
+ * one pinned log entry per iteration).  Semantics are those of the host loop around nos_*_accumulate
+ * (same source for the loop body); only floating-point contraction may differ in the last bits.
+ * With a communicator (nos_ctx_comm_init) each launch is followed by the all-reduce and a one-wave step
+ * kernel; every rank ends with identical bits.  Single-device contexts only (NOS_ERR_UNSUPPORTED
+ * otherwise: use the host loop).  R / t are in-out. */
+typedef struct nos_lm_options {
+  int32_t max_iterations;      /* Options::max_iterations (options.h) */
+  int32_t launches_in_flight;  /* 0 = default (3) */
+  double gradient_tolerance;   /* Options::convergence_handle.gradient_tolerance */
+  double parameter_tolerance;  /* Options::convergence_handle.parameter_tolerance */
+  double* cost_history;        /* NULL, or room for max_iterations costs (one per executed iteration) */
+} nos_lm_options;
+
+typedef struct nos_lm_report {
+  int32_t iterations;   /* loop index at exit: the "iter:" of the reference's stderr line */
+  int32_t ok;           /* 0 if the damped solve met a non-positive pivot */
+  int32_t launches;     /* kernels enqueued (>= iterations executed; the surplus exits at once) */
+  int32_t reserved;
+  double printed_cost;  /* previous_cost at exit: the "COST:" of that line */
+  double last_cost;
+  double final_lambda;
+} nos_lm_report;
+
+int nos_ndt6_solve(nos_dataset* ds, double R[9], double t[3], const nos_loss* loss,
+                   const nos_lm_options* options, nos_lm_report* report);
+int nos_ndt3_solve(nos_dataset* ds, double R2[4], double t2[2], const nos_loss* loss,
+                   const nos_lm_options* options, nos_lm_report* report);
+int nos_reproj_solve(nos_dataset* ds, double R[9], double t[3], const double intr[4],
+                     const nos_loss* loss, double min_depth, const nos_lm_options* options,
+                     nos_lm_report* report);
+
 /* ---- pose-graph optimisation (BASELINE.json configs[4]) --------
  * The reference's PoseGraphOptimizerAnalytic::Solve is an empty loop
  * (NO/pose_graph_optimizer/pose_graph_optimizer_analytic.cc:12-51); only the Ceres path is real.
@@ -321,7 +361,12 @@ int nos_ndt3_time_kernel(nos_dataset* ds, const double R2[4], const double t2[2]
  * kernel launched through this context is bracketed by a HIP event pair recorded on the
  * stream it is launched on (every sample_every-th launch, up to max_launches timed launches per
  * device; the two event records cost about a microsecond of host time each).  _end synchronises
- * and returns the number of timed launches and their mean / min / max duration. */
+ * and returns the number of timed launches and their mean / min / max duration.
+ * sample_every == 0 selects the bracket form for back-to-back launch trains (the device-resident
+ * loop): ONE event is recorded at _begin and one at _end on the launch stream, nothing in between
+ * (an event between two queued kernels would serialise their dispatch and show up in what it
+ * measures); _end returns the launches in between and (t_end - t_begin) / launches as mean = min =
+ * max — an upper bound of the kernel duration that includes whatever else ran in the train. */
 int nos_ctx_profile_begin(nos_ctx* ctx, int max_launches, int sample_every);
 int nos_ctx_profile_end(nos_ctx* ctx, int* n_launches, double* mean_ms, double* min_ms,
                         double* max_ms);

@@ -35,6 +35,7 @@ C_ABI_SYMBOLS = (
     "nos_pgo_matvec", "nos_dataset_destroy", "nos_dataset_size", "nos_dataset_dtype", "nos_dataset_stream_bytes",
     "nos_ndt6_accumulate", "nos_ndt3_accumulate", "nos_reproj_accumulate",
     "nos_ndt6_accumulate_async", "nos_ndt3_accumulate_async", "nos_reproj_accumulate_async",
+    "nos_ndt6_solve", "nos_ndt3_solve", "nos_reproj_solve",
     "nos_ctx_set_launch", "nos_ctx_profile_begin", "nos_ctx_profile_end", "nos_ndt6_time_kernel", "nos_reproj_time_kernel",
     "nos_ndt3_time_kernel", "nos_status_string", "nos_last_error", "nos_version",
 )
@@ -43,6 +44,18 @@ C_ABI_SYMBOLS = (
 class NosLoss(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_int32), ("reserved", ctypes.c_int32),
                 ("a", ctypes.c_double), ("b", ctypes.c_double)]
+
+
+class NosLmOptions(ctypes.Structure):
+    _fields_ = [("max_iterations", ctypes.c_int32), ("launches_in_flight", ctypes.c_int32),
+                ("gradient_tolerance", ctypes.c_double), ("parameter_tolerance", ctypes.c_double),
+                ("cost_history", ctypes.POINTER(ctypes.c_double))]
+
+
+class NosLmReport(ctypes.Structure):
+    _fields_ = [("iterations", ctypes.c_int32), ("ok", ctypes.c_int32), ("launches", ctypes.c_int32),
+                ("reserved", ctypes.c_int32), ("printed_cost", ctypes.c_double), ("last_cost", ctypes.c_double),
+                ("final_lambda", ctypes.c_double)]
 
 
 class NosError(RuntimeError):
@@ -134,6 +147,10 @@ def _declare(lib):
     lib.nos_ndt6_accumulate_async.argtypes = [vp, dp, dp, lp, vp]
     lib.nos_ndt3_accumulate_async.argtypes = [vp, dp, dp, lp, vp]
     lib.nos_reproj_accumulate_async.argtypes = [vp, dp, dp, dp, lp, ctypes.c_double, vp]
+    lmo, lmr = ctypes.POINTER(NosLmOptions), ctypes.POINTER(NosLmReport)
+    lib.nos_ndt6_solve.argtypes = [vp, dp, dp, lp, lmo, lmr]
+    lib.nos_ndt3_solve.argtypes = [vp, dp, dp, lp, lmo, lmr]
+    lib.nos_reproj_solve.argtypes = [vp, dp, dp, dp, lp, ctypes.c_double, lmo, lmr]
     lib.nos_ndt6_time_kernel.argtypes = [vp, dp, dp, lp, i, dp, dp]
     lib.nos_ndt3_time_kernel.argtypes = [vp, dp, dp, lp, i, dp, dp]
     lib.nos_reproj_time_kernel.argtypes = [vp, dp, dp, dp, lp, ctypes.c_double, i, dp, dp]

@@ -137,6 +137,21 @@ class Context:
             pass
 
 
+def _lm_call(fn, where, pre_args, post_args, R, t, max_iterations, gradient_tolerance, parameter_tolerance,
+             launches_in_flight):
+    """Shared body of the device-resident solve methods: returns (R, t, report dict)."""
+    from ._lib import NosLmOptions, NosLmReport
+    hist = np.full(max(int(max_iterations), 1), np.nan)
+    opt = NosLmOptions(int(max_iterations), int(launches_in_flight), float(gradient_tolerance),
+                       float(parameter_tolerance), _dp(hist))
+    rep = NosLmReport()
+    check(fn(*pre_args, _dp(R), _dp(t), *post_args, ctypes.byref(opt), ctypes.byref(rep)), where)
+    executed = int(np.count_nonzero(~np.isnan(hist[:max(int(max_iterations), 0)])))
+    return R, t, {"iterations": rep.iterations, "ok": bool(rep.ok), "launches": rep.launches,
+                  "printed_cost": rep.printed_cost, "last_cost": rep.last_cost, "final_lambda": rep.final_lambda,
+                  "cost_history": hist[:executed].copy()}
+
+
 class _Dataset:
     _n_planes = 0
     _create = _create_dev = _create_rec = None
@@ -234,6 +249,24 @@ class NdtDataset(_Dataset):
         check(self._lib.nos_ndt6_accumulate(self._h, _dp(R), _dp(t), ctypes.byref(l), _dp(out)), "nos_ndt6_accumulate")
         return out
 
+    def solve6(self, R, t, loss=None, max_iterations=100, gradient_tolerance=1e-6, parameter_tolerance=1e-6,
+               launches_in_flight=0):
+        """Whole LM loop on the device (nos_ndt6_solve).  Returns (R[9], t[3], report)."""
+        R = _dvec(R, 9).copy()
+        t = _dvec(t, 3).copy()
+        l = make_loss(loss)
+        return _lm_call(self._lib.nos_ndt6_solve, "nos_ndt6_solve", (self._h,), (ctypes.byref(l),), R, t,
+                        max_iterations, gradient_tolerance, parameter_tolerance, launches_in_flight)
+
+    def solve3(self, R2, t2, loss=None, max_iterations=100, gradient_tolerance=1e-6, parameter_tolerance=1e-6,
+               launches_in_flight=0):
+        """Planar LM loop on the device (nos_ndt3_solve).  Returns (R2[4], t2[2], report)."""
+        R2 = _dvec(R2, 4).copy()
+        t2 = _dvec(t2, 2).copy()
+        l = make_loss(loss)
+        return _lm_call(self._lib.nos_ndt3_solve, "nos_ndt3_solve", (self._h,), (ctypes.byref(l),), R2, t2,
+                        max_iterations, gradient_tolerance, parameter_tolerance, launches_in_flight)
+
     def accumulate6_async(self, R, t, loss, out_tensor):
         """Enqueue on the context stream; result lands in the CUDA float64 tensor out_tensor[28]."""
         R = _dvec(R, 9)
@@ -319,6 +352,17 @@ class ReprojDataset(_Dataset):
         check(self._lib.nos_reproj_accumulate(self._h, _dp(R), _dp(t), _dp(intr), ctypes.byref(l),
                                               ctypes.c_double(min_depth), _dp(out)), "nos_reproj_accumulate")
         return out
+
+    def solve(self, R, t, intr, loss=None, min_depth=0.03, max_iterations=100, gradient_tolerance=1e-6,
+              parameter_tolerance=1e-6, launches_in_flight=0):
+        """Whole LM loop on the device (nos_reproj_solve).  Returns (R[9], t[3], report)."""
+        R = _dvec(R, 9).copy()
+        t = _dvec(t, 3).copy()
+        intr = _dvec(intr, 4)
+        l = make_loss(loss)
+        return _lm_call(self._lib.nos_reproj_solve, "nos_reproj_solve", (self._h,),
+                        (_dp(intr), ctypes.byref(l), ctypes.c_double(min_depth)), R, t,
+                        max_iterations, gradient_tolerance, parameter_tolerance, launches_in_flight)
 
     def accumulate_async(self, R, t, intr, loss, out_tensor, min_depth=0.03):
         R = _dvec(R, 9)

@@ -21,6 +21,8 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+
+#include "host/nos_lm.hpp"
 #include <stdint.h>
 
 namespace nos {
@@ -339,18 +341,54 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// Sums NOUT values per lane over the 64 lanes of a wave with a reduce-scatter butterfly: at every step a lane
+// keeps one half of its values and trades the other half with its partner (lane ^ 32, ^ 16, …), so the number of
+// values halves each time — P + log2(64 / P) cross-lane exchanges in total (P = NOUT rounded up to a power of two)
+// instead of 6·NOUT for NOUT independent butterflies.  The cross-lane exchanges (ds_bpermute) are what bounds this
+// phase: at 28 values and 8 waves per CU the independent form kept the LDS crossbar busy for ≈ 6-12 µs at the end of
+// every launch.  On return lane L holds the wave total of value number  L >> (6 - log2 P)  (lanes that share a value
+// number hold the same total).  Fixed order of additions → bit-identical results run to run.
+template <int NOUT>
+struct WaveScatter {
+  static constexpr int kP = NOUT > 16 ? 32 : (NOUT > 8 ? 16 : 8);
+  static constexpr int kLog2P = kP == 32 ? 5 : (kP == 16 ? 4 : 3);
+  static constexpr int kShift = 6 - kLog2P;  // value number of lane L is L >> kShift
+  __device__ static __forceinline__ double run(const double (&acc)[NOUT]) {
+    double v[kP];
+#pragma unroll
+    for (int k = 0; k < kP; ++k) v[k] = k < NOUT ? acc[k] : 0.0;
+    const int lane = threadIdx.x & (kWave - 1);
+#pragma unroll
+    for (int s = 0; s < kLog2P; ++s) {
+      const int mask = 32 >> s;
+      const int half = kP >> (s + 1);
+      const bool upper = (lane & mask) != 0;
+#pragma unroll
+      for (int j = 0; j < half; ++j) {
+        const double send = upper ? v[j] : v[j + half];
+        const double keep = upper ? v[j + half] : v[j];
+        v[j] = keep + __shfl_xor(send, mask, kWave);
+      }
+    }
+#pragma unroll
+    for (int mask = (32 >> kLog2P); mask > 0; mask >>= 1) v[0] += __shfl_xor(v[0], mask, kWave);
+    return v[0];
+  }
+};
+
 // Sums acc[] over the block and writes one row of kOut doubles.  Fixed order:
-// butterfly inside a wave, then waves 0..W-1.
+// reduce-scatter butterfly inside a wave, then waves 0..W-1.
 template <int NOUT, int BLOCK>
 __device__ __forceinline__ void block_reduce_store(const double (&acc)[NOUT], double* row, bool write_through) {
   constexpr int kWaves = BLOCK / kWave;
   __shared__ double lds[kWaves][NOUT];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x / kWave;
-#pragma unroll
-  for (int k = 0; k < NOUT; ++k) {
-    const double s = wave_sum(acc[k]);
-    if (lane == 0) lds[wave][k] = s;
+  {
+    const double s = WaveScatter<NOUT>::run(acc);
+    constexpr int kShift = WaveScatter<NOUT>::kShift;
+    const int k = lane >> kShift;
+    if ((lane & ((1 << kShift) - 1)) == 0 && k < NOUT) lds[wave][k] = s;
   }
   __syncthreads();
   if (threadIdx.x < NOUT) {
@@ -374,6 +412,29 @@ __device__ __forceinline__ void block_reduce_store(const double (&acc)[NOUT], do
 // cdna_hip_programming.md Guideline 16: storing wave drains (vmcnt(0)) → one lane
 // agent-scope release → asm vmcnt(0) → relaxed agent atomic ticket;  last block: ticket
 // value is the "poll", one lane agent-scope acquire → vmcnt(0) → barrier → plain loads.
+// Device-resident Levenberg-Marquardt loop (nos_*_solve): the pose lives in device memory, every launch reads it
+// from there instead of from its kernel arguments, and the workgroup that finishes the reduction also runs the
+// loop body of the reference (damped 6x6 solve, pose update, convergence tests, λ schedule — the same
+// nos_host::LmAdvance6 / LmAdvance3 the host loop calls) and leaves the new pose for the next launch.  The host
+// only keeps a few launches in flight and watches a log in pinned memory, so consecutive iterations run
+// back-to-back on the GPU without a host round trip in between.
+struct LmDevice {
+  nos_host::LmState st;
+  nos_host::LmSettings settings;
+};
+
+// Layout (in doubles) of one entry of the pinned host log the loop writes per iteration.
+constexpr int kLogOut = 0;        // [0..27] the sums of this iteration
+constexpr int kLogR = 32;         // [32..40] pose after the update
+constexpr int kLogT = 41;         // [41..43]
+constexpr int kLogLambda = 44;
+constexpr int kLogPrevCost = 45;
+constexpr int kLogCost = 46;
+constexpr int kLogIteration = 47;
+constexpr int kLogDone = 48;
+constexpr int kLogOk = 49;
+constexpr int kLogEntryDoubles = 64;
+
 struct FusedFinal {
   unsigned int* counter;           // device words (top counter at [0], 8 group counters at [32 * (1 + g)]), all 0
                                    // before the launch and reset to 0 by the blocks that complete them
@@ -382,10 +443,102 @@ struct FusedFinal {
   unsigned long long* seq_host;    // host-mapped pinned sequence word (may be null)
   unsigned long long seq;          // value stored to *seq_host when the result is complete
   int write_through;               // 1: rows travel as sc1 stores / sc1 loads instead of release / acquire fences
+  LmDevice* lm;                    // device-resident loop state: pose source of this launch (null = pose from arguments)
+  int lm_step;                     // 1: the finishing workgroup also advances the loop; 0: a separate kernel does
 };
 
+__device__ __forceinline__ double uniform_load(const double* p) {
+  // the address is the same for every lane of the grid: keep the value in scalar registers
+  const double v = *p;
+  const unsigned long long u = __double_as_longlong(v);
+  const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)(u & 0xFFFFFFFFull));
+  const unsigned int hi = __builtin_amdgcn_readfirstlane((unsigned int)(u >> 32));
+  return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+
+template <typename T>
+__device__ __forceinline__ void set_pose(Ndt6Params<T>& P, const LmDevice* lm) {
+#pragma unroll
+  for (int k = 0; k < 9; ++k) P.R[k] = T(uniform_load(&lm->st.R[k]));
+#pragma unroll
+  for (int k = 0; k < 3; ++k) P.t[k] = T(uniform_load(&lm->st.t[k]));
+}
+template <typename T>
+__device__ __forceinline__ void set_pose(ReprojParams<T>& P, const LmDevice* lm) {
+#pragma unroll
+  for (int k = 0; k < 9; ++k) P.R[k] = T(uniform_load(&lm->st.R[k]));
+#pragma unroll
+  for (int k = 0; k < 3; ++k) P.t[k] = T(uniform_load(&lm->st.t[k]));
+}
+template <typename T>
+__device__ __forceinline__ void set_pose(Ndt3Params<T>& P, const LmDevice* lm) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) P.R2[k] = T(uniform_load(&lm->st.R[k]));
+#pragma unroll
+  for (int k = 0; k < 2; ++k) P.t2[k] = T(uniform_load(&lm->st.t[k]));
+}
+
+// Launch prologue of the device-resident loop.  Returns true if this launch has nothing to do (the loop already
+// finished): block 0 then only forwards the sequence word so the host's wait completes.
+template <typename Params>
+__device__ __forceinline__ bool lm_prologue(const FusedFinal& fin, Params& P) {
+  if (fin.lm == nullptr) return false;
+  // pose and the done flag are fetched together (one memory round trip at the head of the launch)
+  Params Q = P;
+  set_pose(Q, fin.lm);
+  const int done = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(&fin.lm->st.done));
+  if (done != 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && fin.seq_host != nullptr)
+      __hip_atomic_store(fin.seq_host, fin.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return true;
+  }
+  P = Q;
+  return false;
+}
+
+// Loop body after the sums are known (one lane).  `tot` holds the NOUT sums; the new state goes to device memory
+// for the next launch and, if `entry_host` is set, to the pinned log entry the host is waiting for.
+#ifdef NOS_LM_TIMING
+#define NOS_LM_STAMP(slot) \
+  if (entry_host != nullptr) __hip_atomic_store(entry_host + 50 + (slot), double(wall_clock64()), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+#else
+#define NOS_LM_STAMP(slot)
+#endif
+
+template <int NOUT>
+__device__ __forceinline__ void lm_advance(const double* tot, nos_host::LmState st, const nos_host::LmSettings settings,
+                                           LmDevice* lm, double* entry_host) {
+  NOS_LM_STAMP(2);
+  double out[NOUT];
+#pragma unroll
+  for (int k = 0; k < NOUT; ++k) out[k] = tot[k];
+  if constexpr (NOUT == 28)
+    nos_host::LmAdvance6(settings, out, &st);
+  else
+    nos_host::LmAdvance3(settings, out, &st);
+  NOS_LM_STAMP(3);
+  lm->st = st;
+  if (entry_host != nullptr) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+      __hip_atomic_store(entry_host + kLogR + k, st.R[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      __hip_atomic_store(entry_host + kLogT + k, st.t[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(entry_host + kLogLambda, st.lambda, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(entry_host + kLogPrevCost, st.previous_cost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(entry_host + kLogCost, st.cost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(entry_host + kLogIteration, double(st.iteration), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(entry_host + kLogDone, double(st.done), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(entry_host + kLogOk, double(st.ok), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  NOS_LM_STAMP(4);
+}
+
 template <int NOUT, int BLOCK>
-__device__ __forceinline__ void finish_in_last_block(const double* partials, const FusedFinal& fin) {
+__device__ __forceinline__ void finish_in_last_block(const double* partials, const FusedFinal& fin,
+                                                     unsigned long long t_start = 0) {
+  (void)t_start;
   __shared__ unsigned int s_last;
   constexpr int kCols = 32;
   constexpr int kSlices = BLOCK / kCols;
@@ -429,20 +582,45 @@ __device__ __forceinline__ void finish_in_last_block(const double* partials, con
   }
   __syncthreads();
   if (s_last == 0u) return;  // block-uniform
+#ifdef NOS_LM_TIMING
+  if (threadIdx.x == 0 && fin.out_host != nullptr && fin.lm != nullptr) {
+    __hip_atomic_store(fin.out_host + 50, double(t_start), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(fin.out_host + 51, double(wall_clock64()), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+#endif
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // no instruction: keeps the loads below the ticket
   const int col = threadIdx.x % kCols;
   const int slice = threadIdx.x / kCols;
+  // the loop state is requested now so that its latency hides behind the row sums
+  const bool step_here = fin.lm != nullptr && fin.lm_step != 0;  // grid-uniform
+  nos_host::LmState st_pre;
+  nos_host::LmSettings settings_pre;
+  if (step_here && threadIdx.x == 0) {
+    st_pre = fin.lm->st;
+    settings_pre = fin.lm->settings;
+  }
+  // Thread (slice, col) adds rows slice, slice + S, slice + 2S, … in that order.  Sixteen row loads are put in flight
+  // before the first add: the loop is latency bound (each row comes from another XCD's L2 / memory).
+  constexpr int kUnroll = 16;
   double s = 0.0;
   if (col < NOUT) {
-    if (wt) {
-      for (uint32_t r = slice; r < gridDim.x; r += kSlices)
-        s += __hip_atomic_load(partials + size_t(r) * NOUT + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      for (uint32_t r = slice; r < gridDim.x; r += kSlices) s += partials[size_t(r) * NOUT + col];
+    const double* p = partials + col;
+    for (uint32_t r = slice; r < gridDim.x; r += kUnroll * kSlices) {
+      double v[kUnroll];
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        const uint32_t rr = r + u * kSlices;
+        const double* q = p + size_t(rr < gridDim.x ? rr : r) * NOUT;  // clamped address, value masked below
+        const double x = wt ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q;
+        v[u] = rr < gridDim.x ? x : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) s += v[u];
     }
   }
   red[slice][col] = s;
   __syncthreads();
+  __shared__ double s_tot[NOUT];
   if (threadIdx.x < NOUT) {
     double tot = 0.0;
 #pragma unroll
@@ -450,6 +628,11 @@ __device__ __forceinline__ void finish_in_last_block(const double* partials, con
     if (fin.out_dev != nullptr) fin.out_dev[threadIdx.x] = tot;
     if (fin.out_host != nullptr)
       __hip_atomic_store(fin.out_host + threadIdx.x, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (step_here) s_tot[threadIdx.x] = tot;
+  }
+  if (step_here) {
+    __syncthreads();
+    if (threadIdx.x == 0) lm_advance<NOUT>(s_tot, st_pre, settings_pre, fin.lm, fin.out_host);
   }
   if (threadIdx.x < kWave) {
     // results leave through lanes 0..NOUT-1 of wave 0: drain them, then one lane publishes
@@ -480,6 +663,16 @@ __global__ __launch_bounds__(BLOCK, MINW) void assemble_kernel(TiledLayout L,
   constexpr int kOut = Problem::kOut;
   constexpr uint32_t kChunk = BLOCK * ITEMS;
   const T* __restrict__ base = static_cast<const T*>(L.base);
+
+#ifdef NOS_LM_TIMING
+  const unsigned long long t_start = wall_clock64();
+#else
+  const unsigned long long t_start = 0;
+#endif
+  if (lm_prologue(fin, P)) return;  // grid-uniform
+#ifdef NOS_LM_TIMING
+  const unsigned long long t_prologue = wall_clock64() + (unsigned long long)(*reinterpret_cast<const T*>(&P) * T(0));  // after the pose arrived
+#endif
 
   T acc[kOut];
 #pragma unroll
@@ -542,8 +735,19 @@ __global__ __launch_bounds__(BLOCK, MINW) void assemble_kernel(TiledLayout L,
   double dacc[kOut];
 #pragma unroll
   for (int k = 0; k < kOut; ++k) dacc[k] = double(acc[k]);
+#ifdef NOS_LM_TIMING
+  const unsigned long long t_loop = wall_clock64() + (unsigned long long)(dacc[0] * 0.0);  // after the item math
+#endif
   block_reduce_store<kOut, BLOCK>(dacc, partials + size_t(blockIdx.x) * kOut, fin.write_through != 0);
-  if (fin.counter != nullptr) finish_in_last_block<kOut, BLOCK>(partials, fin);
+#ifdef NOS_LM_TIMING
+  if (threadIdx.x == 0 && fin.out_host != nullptr && fin.lm != nullptr) {
+    // overwritten by every block; the last writer is (almost always) the finishing block
+    __hip_atomic_store(fin.out_host + 56, double(t_prologue - t_start), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(fin.out_host + 57, double(t_loop - t_prologue), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(fin.out_host + 58, double(wall_clock64() - t_loop), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+#endif
+  if (fin.counter != nullptr) finish_in_last_block<kOut, BLOCK>(partials, fin, t_start);
 }
 
 // ---------------------------------------------------------------- voxel-indexed variant
@@ -599,6 +803,8 @@ __global__ __launch_bounds__(BLOCK, MINW) void assemble_indexed_kernel(IndexedLa
   constexpr int kOut = Problem::kOut;
   const T* __restrict__ pts = static_cast<const T*>(L.points);
   const T* __restrict__ table = static_cast<const T*>(L.table);
+  if (lm_prologue(fin, P)) return;  // grid-uniform
+
   T acc[kOut];
 #pragma unroll
   for (int k = 0; k < kOut; ++k) acc[k] = T(0);
@@ -692,12 +898,56 @@ __global__ __launch_bounds__(256) void build_voxel_table_kernel(const double* __
 }
 
 // sort keys for the voxel ordering: slot-0 voxel id, absent (-1) last
-static __global__ __launch_bounds__(256) void index_sort_key_kernel(const int32_t* __restrict__ idx0, uint64_t n,
+__attribute__((unused)) static __global__ __launch_bounds__(256) void index_sort_key_kernel(const int32_t* __restrict__ idx0, uint64_t n,
                                                              uint32_t* __restrict__ keys, uint32_t* __restrict__ ids) {
   const uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x;
   if (i >= n) return;
   keys[i] = idx0[i] < 0 ? 0xFFFFFFFFu : uint32_t(idx0[i]);
   ids[i] = uint32_t(i);
+}
+
+// Device-resident loop: initial state (one lane; the arguments travel by value, no copy is needed).
+struct LmInitArgs {
+  double R[9];
+  double t[3];
+  nos_host::LmSettings settings;
+  int dof;  // 6 or 3
+};
+__attribute__((unused)) static __global__ void lm_init_kernel(LmDevice* lm, LmInitArgs a) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  nos_host::LmState st;
+  if (a.dof == 6)
+    nos_host::LmInit6(&st, a.R, a.t, a.settings.max_iterations);
+  else
+    nos_host::LmInit3(&st, a.R, a.t, a.settings.max_iterations);
+  lm->st = st;
+  lm->settings = a.settings;
+}
+
+// Device-resident loop, stand-alone step (one wave): used when the sums come out of an RCCL all-reduce (or when
+// the in-launch step is switched off).  Reads the sums from `sums`, publishes them and the new state to the pinned
+// log entry, then the sequence word.
+template <int NOUT>
+__global__ __launch_bounds__(64) void lm_step_kernel(const double* __restrict__ sums, LmDevice* lm, double* entry_host,
+                                                     unsigned long long* seq_host, unsigned long long seq) {
+  __shared__ double s_tot[NOUT];
+  const int done = *reinterpret_cast<const volatile int*>(&lm->st.done);  // loop finished earlier: forward seq only
+  if (done == 0) {
+    if (threadIdx.x < NOUT) {
+      const double v = sums[threadIdx.x];
+      s_tot[threadIdx.x] = v;
+      if (entry_host != nullptr)
+        __hip_atomic_store(entry_host + kLogOut + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) lm_advance<NOUT>(s_tot, lm->st, lm->settings, lm, entry_host);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (threadIdx.x == 0 && seq_host != nullptr) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(seq_host, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // Fixed-order sum of the block rows: thread (slice, col) adds rows slice, slice+S, …;

@@ -47,6 +47,29 @@ void FillReport(const nos_host::LmReport& lm, int status, HipSolveReport* rep) {
   rep->status = status;
 }
 
+// Device-resident loop when the options allow it and the context supports it.  Returns true if the loop ran on
+// the device (lm / status filled in); false = the caller runs the host loop.
+template <typename SolveFn>
+bool TryDeviceLoop(const HipOptions& hip, const Options& options, SolveFn&& solve, nos_host::LmReport* lm, int* status) {
+  if (!hip.device_loop) return false;
+  nos_lm_options o{};
+  o.max_iterations = options.max_iterations;
+  o.launches_in_flight = 0;
+  o.gradient_tolerance = options.convergence_handle.gradient_tolerance;
+  o.parameter_tolerance = options.convergence_handle.parameter_tolerance;
+  o.cost_history = nullptr;
+  nos_lm_report r{};
+  const int rc = solve(&o, &r);
+  if (rc == NOS_ERR_UNSUPPORTED) return false;  // multi-device context: host loop sums the shards
+  *status = rc;
+  lm->iterations = r.iterations;
+  lm->printed_cost = r.printed_cost;
+  lm->last_cost = r.last_cost;
+  lm->final_lambda = r.final_lambda;
+  lm->ok = rc == NOS_OK && r.ok != 0;
+  return true;
+}
+
 template <typename PoseT>
 void ReadPose(const PoseT& pose, double t[3], double R[9]) {
   for (int i = 0; i < 3; ++i) {
@@ -203,16 +226,20 @@ bool MahalanobisDistanceMinimizerHip::RunLoop(const Options& options, nos_datase
   double t[3], R[9];
   ReadPose(*pose, t, R);
   int status = NOS_OK;
-  const nos_host::LmReport lm = nos_host::RunLm6(
-      SettingsFrom(options),
-      [&](const double* Rc, const double* tc, double* out28) {
-        status = nos_ndt6_accumulate(dataset, Rc, tc, &loss, out28);
-        return status == NOS_OK;
-      },
-      t, R);
+  nos_host::LmReport lm;
+  if (!TryDeviceLoop(hip_options_, options,
+                     [&](const nos_lm_options* o, nos_lm_report* r) { return nos_ndt6_solve(dataset, R, t, &loss, o, r); },
+                     &lm, &status))
+    lm = nos_host::RunLm6(
+        SettingsFrom(options),
+        [&](const double* Rc, const double* tc, double* out28) {
+          status = nos_ndt6_accumulate(dataset, Rc, tc, &loss, out28);
+          return status == NOS_OK;
+        },
+        t, R);
   FillReport(lm, status, &report_);
   if (!lm.ok) {
-    if (status != NOS_OK) ReportFailure("nos_ndt6_accumulate", status);
+    if (status != NOS_OK) ReportFailure("nos_ndt6_accumulate / nos_ndt6_solve", status);
     return false;
   }
   if (hip_options_.print_cost_line)
@@ -228,16 +255,20 @@ bool MahalanobisDistanceMinimizerHip3DOF::RunLoop(const Options& options, nos_da
   double R2[4] = {pose->linear()(0, 0), pose->linear()(0, 1), pose->linear()(1, 0), pose->linear()(1, 1)};
   double t2[2] = {pose->translation()(0), pose->translation()(1)};
   int status = NOS_OK;
-  const nos_host::LmReport lm = nos_host::RunLm3(
-      SettingsFrom(options),
-      [&](const double* Rc, const double* tc, double* out10) {
-        status = nos_ndt3_accumulate(dataset, Rc, tc, &loss, out10);
-        return status == NOS_OK;
-      },
-      t2, R2);
+  nos_host::LmReport lm;
+  if (!TryDeviceLoop(hip_options_, options,
+                     [&](const nos_lm_options* o, nos_lm_report* r) { return nos_ndt3_solve(dataset, R2, t2, &loss, o, r); },
+                     &lm, &status))
+    lm = nos_host::RunLm3(
+        SettingsFrom(options),
+        [&](const double* Rc, const double* tc, double* out10) {
+          status = nos_ndt3_accumulate(dataset, Rc, tc, &loss, out10);
+          return status == NOS_OK;
+        },
+        t2, R2);
   FillReport(lm, status, &report_);
   if (!lm.ok) {
-    if (status != NOS_OK) ReportFailure("nos_ndt3_accumulate", status);
+    if (status != NOS_OK) ReportFailure("nos_ndt3_accumulate / nos_ndt3_solve", status);
     return false;
   }
   if (hip_options_.print_cost_line)
@@ -307,17 +338,23 @@ bool ReprojectionErrorMinimizerHip::Solve(const Options& options, const std::vec
                           camera_intrinsics.cy};
   double t[3], R[9];
   ReadPose(*pose, t, R);
-  const nos_host::LmReport lm = nos_host::RunLm6(
-      SettingsFrom(options),
-      [&](const double* Rc, const double* tc, double* out28) {
-        status = nos_reproj_accumulate(dataset, Rc, tc, intr, &loss, kMinDepth, out28);
-        return status == NOS_OK;
-      },
-      t, R);
+  nos_host::LmReport lm;
+  if (!TryDeviceLoop(hip_options_, options,
+                     [&](const nos_lm_options* o, nos_lm_report* r) {
+                       return nos_reproj_solve(dataset, R, t, intr, &loss, kMinDepth, o, r);
+                     },
+                     &lm, &status))
+    lm = nos_host::RunLm6(
+        SettingsFrom(options),
+        [&](const double* Rc, const double* tc, double* out28) {
+          status = nos_reproj_accumulate(dataset, Rc, tc, intr, &loss, kMinDepth, out28);
+          return status == NOS_OK;
+        },
+        t, R);
   nos_dataset_destroy(dataset);
   FillReport(lm, status, &report_);
   if (!lm.ok) {
-    if (status != NOS_OK) ReportFailure("nos_reproj_accumulate", status);
+    if (status != NOS_OK) ReportFailure("nos_reproj_accumulate / nos_reproj_solve", status);
     return false;
   }
   if (hip_options_.print_cost_line)

@@ -33,6 +33,8 @@ struct HipOptions {
   std::vector<int> device_ids{0};  // one shard per entry (contiguous ranges of correspondences)
   int dtype{NOS_F64};              // NOS_F64 (scalar-class arithmetic) or NOS_F32 (SIMD-class arithmetic)
   bool print_cost_line{true};      // the reference's "COST: <previous_cost>, iter: <n>" stderr line
+  bool device_loop{true};          // run the whole LM loop device-resident (nos_*_solve); false = host loop around
+                                   // nos_*_accumulate.  Multi-device contexts always use the host loop.
 };
 
 // What the last Solve() did (additive; the reference exposes only the stderr line).

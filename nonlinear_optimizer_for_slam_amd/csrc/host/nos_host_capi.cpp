@@ -28,7 +28,8 @@ std::shared_ptr<LossFunction> MakeLoss(int kind, double a, double b) {
 HipOptions MakeHipOptions(int dtype, const int* device_ids, int n_devices, int print_cost_line) {
   HipOptions h;
   h.dtype = dtype;
-  h.print_cost_line = print_cost_line != 0;
+  h.print_cost_line = (print_cost_line & 1) != 0;  // flag word: bit 0 = print the COST line, bit 1 = host loop
+  h.device_loop = (print_cost_line & 2) == 0;
   if (device_ids != nullptr && n_devices > 0) h.device_ids.assign(device_ids, device_ids + n_devices);
   return h;
 }
@@ -295,7 +296,8 @@ extern "C" int nos_host_ndt_solve_dataset(int dof, nos_dataset* dataset, int los
   namespace mdm = nonlinear_optimizer::mahalanobis_distance_minimizer;
   try {
     HipOptions hip;
-    hip.print_cost_line = print_cost_line != 0;
+    hip.print_cost_line = (print_cost_line & 1) != 0;
+    hip.device_loop = (print_cost_line & 2) == 0;
     std::unique_ptr<mdm::MahalanobisDistanceMinimizerHip> solver;
     if (dof == 3)
       solver = std::make_unique<mdm::MahalanobisDistanceMinimizerHip3DOF>(hip);

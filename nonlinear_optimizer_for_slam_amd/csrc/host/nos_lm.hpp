@@ -13,8 +13,18 @@
 #define NOS_LM_HPP_
 
 #include <algorithm>
+#include <cfloat>
 #include <cmath>
 #include <limits>
+
+// The step of the loop (LmAdvance6 / LmAdvance3 and what they call) also compiles as HIP device code: the
+// device-resident loop of libnos_hip.so (nos_*_solve) runs the very same function in the last workgroup of each
+// launch, so host loop and device loop cannot drift apart.
+#if defined(__HIPCC__)
+#define NOS_HD __host__ __device__
+#else
+#define NOS_HD
+#endif
 
 #if defined(NOS_USE_EIGEN) && __has_include(<Eigen/Dense>)
 #include <Eigen/Dense>
@@ -30,11 +40,11 @@ struct Quat {  // w, x, y, z
 // Rotation matrix (row-major) → unit quaternion, the branch structure Eigen's
 // Quaternion(Matrix3) uses, so the starting orientation equals the reference's
 // `Orientation optimized_orientation(initial_pose.rotation())`.
-inline Quat QuatFromMatrix(const double R[9]) {
+NOS_HD inline Quat QuatFromMatrix(const double R[9]) {
   Quat q;
   const double tr = R[0] + R[4] + R[8];
   if (tr > 0.0) {
-    const double s = std::sqrt(tr + 1.0);
+    const double s = sqrt(tr + 1.0);
     const double f = 0.5 / s;
     q.w = 0.5 * s;
     q.x = (R[7] - R[5]) * f;
@@ -45,7 +55,7 @@ inline Quat QuatFromMatrix(const double R[9]) {
   int i = (R[4] > R[0]) ? 1 : 0;
   if (R[8] > R[4 * i]) i = 2;
   const int j = (i + 1) % 3, k = (j + 1) % 3;
-  const double s = std::sqrt(R[4 * i] - R[4 * j] - R[4 * k] + 1.0);
+  const double s = sqrt(R[4 * i] - R[4 * j] - R[4 * k] + 1.0);
   const double f = 0.5 / s;
   double v[3];
   v[i] = 0.5 * s;
@@ -58,7 +68,7 @@ inline Quat QuatFromMatrix(const double R[9]) {
   return q;
 }
 
-inline void QuatToMatrix(const Quat& q, double R[9]) {
+NOS_HD inline void QuatToMatrix(const Quat& q, double R[9]) {
   const double tx = 2.0 * q.x, ty = 2.0 * q.y, tz = 2.0 * q.z;
   const double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
   const double txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
@@ -76,9 +86,9 @@ inline void QuatToMatrix(const Quat& q, double R[9]) {
 
 // so(3) → quaternion, MahalanobisDistanceMinimizer::ComputeQuaternion
 // (NO/mahalanobis_distance_minimizer/mahalanobis_distance_minimizer.cc:20-33).
-inline Quat ExpQuat(const double w[3]) {
+NOS_HD inline Quat ExpQuat(const double w[3]) {
   Quat q;
-  const double theta = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+  const double theta = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
   if (theta < 1e-6) {
     q.w = 1.0;
     q.x = 0.5 * w[0];
@@ -86,8 +96,8 @@ inline Quat ExpQuat(const double w[3]) {
     q.z = 0.5 * w[2];
   } else {
     const double half = 0.5 * theta;
-    const double k = std::sin(half) / theta;
-    q.w = std::cos(half);
+    const double k = sin(half) / theta;
+    q.w = cos(half);
     q.x = k * w[0];
     q.y = k * w[1];
     q.z = k * w[2];
@@ -96,14 +106,14 @@ inline Quat ExpQuat(const double w[3]) {
 }
 
 // q ← normalize(q ⊗ dq)
-inline void RightMultiplyNormalize(Quat* q, const Quat& d) {
+NOS_HD inline void RightMultiplyNormalize(Quat* q, const Quat& d) {
   const Quat a = *q;
   Quat r;
   r.w = a.w * d.w - a.x * d.x - a.y * d.y - a.z * d.z;
   r.x = a.w * d.x + a.x * d.w + a.y * d.z - a.z * d.y;
   r.y = a.w * d.y + a.y * d.w + a.z * d.x - a.x * d.z;
   r.z = a.w * d.z + a.z * d.w + a.x * d.y - a.y * d.x;
-  const double n = std::sqrt(r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w);
+  const double n = sqrt(r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w);
   q->w = r.w / n;
   q->x = r.x / n;
   q->y = r.y / n;
@@ -114,8 +124,8 @@ inline void RightMultiplyNormalize(Quat* q, const Quat& d) {
 // multiplicative damping the normal matrix is SPD, so no pivoting is required; a
 // non-positive pivot reports failure instead of producing garbage.
 template <int N>
-inline bool SolveLdlt(const double* A, const double* b, double* x) {
-#ifdef NOS_HAVE_EIGEN
+NOS_HD inline bool SolveLdlt(const double* A, const double* b, double* x) {
+#if defined(NOS_HAVE_EIGEN) && !defined(__HIP_DEVICE_COMPILE__)
   using Mat = Eigen::Matrix<double, N, N, Eigen::RowMajor>;
   using Vec = Eigen::Matrix<double, N, 1>;
   Eigen::Map<const Mat> Am(A);
@@ -129,7 +139,7 @@ inline bool SolveLdlt(const double* A, const double* b, double* x) {
   for (int j = 0; j < N; ++j) {
     double d = A[N * j + j];
     for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k] * D[k];
-    if (!(d > 0.0) || !std::isfinite(d)) return false;
+    if (!(d > 0.0) || !(d <= DBL_MAX)) return false;
     D[j] = d;
     L[j][j] = 1.0;
     for (int i = j + 1; i < N; ++i) {
@@ -156,7 +166,7 @@ inline bool SolveLdlt(const double* A, const double* b, double* x) {
 
 // out = {upper triangle row-major | gradient | cost}  →  damped step  δ = -(H∘(1+λ on diag))⁻¹ g
 template <int N>
-inline bool DampedStep(const double* out, double lambda, double* step) {
+NOS_HD inline bool DampedStep(const double* out, double lambda, double* step) {
   double H[N * N], mg[N];
   int k = 0;
   for (int r = 0; r < N; ++r)
@@ -171,10 +181,10 @@ inline bool DampedStep(const double* out, double lambda, double* step) {
 }
 
 template <int N>
-inline double Norm(const double* v) {
+NOS_HD inline double Norm(const double* v) {
   double s = 0.0;
   for (int i = 0; i < N; ++i) s += v[i] * v[i];
-  return std::sqrt(s);
+  return sqrt(s);
 }
 
 struct LmSettings {
@@ -194,82 +204,137 @@ struct LmReport {
 constexpr double kMinLambda = 1e-6;  // constexpr in the reference too (…_analytic_simd.cc:30-31),
 constexpr double kMaxLambda = 1e-2;  // not Options::optimization_handle
 
-// 6-DoF loop.  `accumulate(R, t, out28)` returns false on failure.
-template <typename Accumulate>
-inline LmReport RunLm6(const LmSettings& s, Accumulate&& accumulate, double t[3], double R[9]) {
-  LmReport rep;
-  Quat q = QuatFromMatrix(R);
+// Everything the loop carries from one iteration to the next.  6-DoF: orientation q (R is its matrix, refreshed
+// after every update) and translation t.  Planar: R[0..3] is the 2x2 rotation, t[0..1] the translation.
+struct LmState {
+  double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  double t[3] = {0, 0, 0};
+  Quat q;
   double lambda = 1e-3;
-  double previous_cost = std::numeric_limits<double>::max();
+  double previous_cost = DBL_MAX;  // std::numeric_limits<double>::max() in the reference
   double cost = 0.0;
-  int it = 0;
-  for (; it < s.max_iterations; ++it) {
-    double Rc[9], out[28], step[6];
-    QuatToMatrix(q, Rc);
-    if (!accumulate(Rc, t, out)) {
-      rep.ok = false;
-      break;
-    }
-    cost = out[27];
-    if (!DampedStep<6>(out, lambda, step)) {
-      rep.ok = false;
-      break;
-    }
-    t[0] += step[0];
-    t[1] += step[1];
-    t[2] += step[2];
-    RightMultiplyNormalize(&q, ExpQuat(step + 3));
-    if (Norm<6>(step) < s.parameter_tolerance) break;
-    if (Norm<6>(out + 21) < s.gradient_tolerance) break;
-    lambda = std::clamp(lambda * (cost > previous_cost ? 2.0 : 0.6), kMinLambda, kMaxLambda);
-    previous_cost = cost;
+  int iteration = 0;  // loop index; at exit the "iter:" of the reference's stderr line
+  int done = 0;       // 1 once a convergence test fired, the iteration budget ran out or a solve failed
+  int ok = 1;         // 0 if the damped solve failed
+};
+
+NOS_HD inline void LmInit6(LmState* st, const double R[9], const double t[3], int max_iterations) {
+  *st = LmState();
+  st->q = QuatFromMatrix(R);
+  QuatToMatrix(st->q, st->R);
+  for (int k = 0; k < 3; ++k) st->t[k] = t[k];
+  st->done = max_iterations <= 0 ? 1 : 0;
+}
+
+NOS_HD inline void LmInit3(LmState* st, const double R2[4], const double t2[2], int max_iterations) {
+  *st = LmState();
+  for (int k = 0; k < 4; ++k) st->R[k] = R2[k];
+  st->t[0] = t2[0];
+  st->t[1] = t2[1];
+  st->done = max_iterations <= 0 ? 1 : 0;
+}
+
+NOS_HD inline double NextLambda(double lambda, double cost, double previous_cost) {
+  const double l = lambda * (cost > previous_cost ? 2.0 : 0.6);
+  return l < kMinLambda ? kMinLambda : (l > kMaxLambda ? kMaxLambda : l);
+}
+
+// One pass of the loop body after ComputeCostAndDerivatives: damped solve, pose update, the two convergence
+// tests (after the update, as in the reference), λ schedule.  `out` = {21 H upper | 6 g | cost} evaluated at
+// st->R, st->t.
+NOS_HD inline void LmAdvance6(const LmSettings& s, const double out[28], LmState* st) {
+  double step[6];
+  st->cost = out[27];
+  if (!DampedStep<6>(out, st->lambda, step)) {
+    st->ok = 0;
+    st->done = 1;
+    return;
   }
-  QuatToMatrix(q, R);
-  rep.iterations = it;
-  rep.printed_cost = previous_cost;
-  rep.last_cost = cost;
-  rep.final_lambda = lambda;
+  st->t[0] += step[0];
+  st->t[1] += step[1];
+  st->t[2] += step[2];
+  RightMultiplyNormalize(&st->q, ExpQuat(step + 3));
+  QuatToMatrix(st->q, st->R);
+  if (Norm<6>(step) < s.parameter_tolerance || Norm<6>(out + 21) < s.gradient_tolerance) {
+    st->done = 1;
+    return;
+  }
+  st->lambda = NextLambda(st->lambda, st->cost, st->previous_cost);
+  st->previous_cost = st->cost;
+  if (++st->iteration >= s.max_iterations) st->done = 1;
+}
+
+// Planar form; `out` = {6 H upper | 3 g | cost}.
+NOS_HD inline void LmAdvance3(const LmSettings& s, const double out[10], LmState* st) {
+  double step[3];
+  st->cost = out[9];
+  if (!DampedStep<3>(out, st->lambda, step)) {
+    st->ok = 0;
+    st->done = 1;
+    return;
+  }
+  st->t[0] += step[0];
+  st->t[1] += step[1];
+  const double c = cos(step[2]), sn = sin(step[2]);
+  const double a = st->R[0], b = st->R[1], d = st->R[2], e = st->R[3];
+  st->R[0] = a * c + b * sn;  // linear ← linear · Rot2(δθ)   (Isometry2d::rotate)
+  st->R[1] = b * c - a * sn;
+  st->R[2] = d * c + e * sn;
+  st->R[3] = e * c - d * sn;
+  if (Norm<3>(step) < s.parameter_tolerance || Norm<3>(out + 6) < s.gradient_tolerance) {
+    st->done = 1;
+    return;
+  }
+  st->lambda = NextLambda(st->lambda, st->cost, st->previous_cost);
+  st->previous_cost = st->cost;
+  if (++st->iteration >= s.max_iterations) st->done = 1;
+}
+
+inline LmReport ReportOf(const LmState& st) {
+  LmReport rep;
+  rep.iterations = st.iteration;
+  rep.printed_cost = st.previous_cost;
+  rep.last_cost = st.cost;
+  rep.final_lambda = st.lambda;
+  rep.ok = st.ok != 0;
   return rep;
 }
 
-// Planar loop: state is the 2x2 rotation (row-major) and (x, y).
-// `accumulate(R2, t2, out10)`.
+// 6-DoF loop.  `accumulate(R, t, out28)` returns false on failure.
+template <typename Accumulate>
+inline LmReport RunLm6(const LmSettings& s, Accumulate&& accumulate, double t[3], double R[9]) {
+  LmState st;
+  LmInit6(&st, R, t, s.max_iterations);
+  while (!st.done) {
+    double out[28];
+    if (!accumulate(st.R, st.t, out)) {
+      st.ok = 0;
+      break;
+    }
+    LmAdvance6(s, out, &st);
+  }
+  for (int k = 0; k < 9; ++k) R[k] = st.R[k];
+  for (int k = 0; k < 3; ++k) t[k] = st.t[k];
+  return ReportOf(st);
+}
+
+// Planar loop: state is the 2x2 rotation (row-major) and (x, y).  `accumulate(R2, t2, out10)`.
 template <typename Accumulate>
 inline LmReport RunLm3(const LmSettings& s, Accumulate&& accumulate, double t2[2], double R2[4]) {
-  LmReport rep;
-  double lambda = 1e-3;
-  double previous_cost = std::numeric_limits<double>::max();
-  double cost = 0.0;
-  int it = 0;
-  for (; it < s.max_iterations; ++it) {
-    double out[10], step[3];
-    if (!accumulate(R2, t2, out)) {
-      rep.ok = false;
+  LmState st;
+  LmInit3(&st, R2, t2, s.max_iterations);
+  while (!st.done) {
+    double out[10];
+    if (!accumulate(st.R, st.t, out)) {
+      st.ok = 0;
       break;
     }
-    cost = out[9];
-    if (!DampedStep<3>(out, lambda, step)) {
-      rep.ok = false;
-      break;
-    }
-    t2[0] += step[0];
-    t2[1] += step[1];
-    const double c = std::cos(step[2]), sn = std::sin(step[2]);
-    const double a = R2[0], b = R2[1], d = R2[2], e = R2[3];
-    R2[0] = a * c + b * sn;  // linear ← linear · Rot2(δθ)   (Isometry2d::rotate)
-    R2[1] = b * c - a * sn;
-    R2[2] = d * c + e * sn;
-    R2[3] = e * c - d * sn;
-    if (Norm<3>(step) < s.parameter_tolerance) break;
-    if (Norm<3>(out + 6) < s.gradient_tolerance) break;
-    lambda = std::clamp(lambda * (cost > previous_cost ? 2.0 : 0.6), kMinLambda, kMaxLambda);
-    previous_cost = cost;
+    LmAdvance3(s, out, &st);
   }
-  rep.iterations = it;
-  rep.printed_cost = previous_cost;
-  rep.last_cost = cost;
-  rep.final_lambda = lambda;
-  return rep;
+  for (int k = 0; k < 4; ++k) R2[k] = st.R[k];
+  t2[0] = st.t[0];
+  t2[1] = st.t[1];
+  return ReportOf(st);
 }
 
 }  // namespace nos_host

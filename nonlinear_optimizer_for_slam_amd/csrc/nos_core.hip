@@ -209,7 +209,8 @@ int launch_assemble_raw(const nos_dataset* ds, const Shard& sh, const Request& r
 int launch_assemble(const nos_dataset* ds, const Shard& sh, const Request& rq, double* partials,
                     const nos::FusedFinal& fin, hipStream_t stream, int* rows_out) {
   DeviceSlot& slot = ds->ctx->slots[sh.slot];
-  const bool prof = slot.prof_on && (slot.prof_launches++ % slot.prof_every) == 0 &&
+  if (slot.prof_on && slot.prof_every == 0) ++slot.prof_launches;  // bracket form: count only
+  const bool prof = slot.prof_on && slot.prof_every > 0 && (slot.prof_launches++ % slot.prof_every) == 0 &&
                     slot.prof_used + 2 <= slot.prof_events.size();
   if (prof) NOS_HIP_CHECK(hipEventRecord(slot.prof_events[slot.prof_used], stream));
   const int rc = launch_assemble_raw(ds, sh, rq, partials, fin, stream, rows_out);
@@ -341,14 +342,13 @@ __global__ void publish_kernel(const double* __restrict__ src, int n, double* ds
 // Spin on the host-mapped sequence word the last block stores after the result; falls back
 // to a stream synchronise if the word has not arrived after a generous bound, so a protocol
 // error can never hang the caller.
-int wait_for_sequence(DeviceSlot& slot) {
+int wait_for_sequence(DeviceSlot& slot, unsigned long long want) {
   volatile unsigned long long* seq = reinterpret_cast<volatile unsigned long long*>(slot.h_out + kSeqSlot);
-  const unsigned long long want = slot.seq;
-  for (long spins = 0; *seq != want; ++spins) {
+  for (long spins = 0; *seq < want; ++spins) {
     if (spins > 2000000) {
       NOS_HIP_CHECK(hipSetDevice(slot.device));
       NOS_HIP_CHECK(hipStreamSynchronize(slot.stream));
-      if (*seq != want) return fail(NOS_ERR_HIP, "fused final reduce did not publish its sequence word");
+      if (*seq < want) return fail(NOS_ERR_HIP, "fused final reduce did not publish its sequence word");
       break;
     }
 #if defined(__x86_64__)
@@ -358,6 +358,7 @@ int wait_for_sequence(DeviceSlot& slot) {
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
   return NOS_OK;
 }
+int wait_for_sequence(DeviceSlot& slot) { return wait_for_sequence(slot, slot.seq); }
 
 // Blocking accumulate over every shard; shard sums are added on the host in shard order
 // (the reference sums its per-thread partials the same way).
@@ -480,6 +481,119 @@ int time_kernel(nos_dataset* ds, const Request& rq, int repeats, double* kernel_
   NOS_HIP_CHECK(hipEventElapsedTime(&ms12, slot.ev1, slot.ev2));
   if (kernel_ms) *kernel_ms = double(ms01) / repeats;
   if (total_ms) *total_ms = double(ms12) / repeats;
+  return NOS_OK;
+}
+
+// Device-resident Levenberg-Marquardt loop (see nos::LmDevice).  The host keeps `window` launches in flight and
+// reads one pinned log entry per finished iteration; nothing on the host sits between two consecutive kernels.
+// With an RCCL communicator every launch is followed by the all-reduce of its sums and a one-wave step kernel, so
+// all ranks advance identical states in lock-step without host synchronisation either.
+int lm_solve(nos_dataset* ds, const Request& rq, const nos_lm_options* opt, double* R, int nR, double* t, int nt,
+             nos_lm_report* report) {
+  if (!opt) return fail(NOS_ERR_INVALID_ARGUMENT, "options pointer is NULL");
+  if (ds->shards.size() != 1)
+    return fail(NOS_ERR_UNSUPPORTED, "the device-resident loop needs a single-device context (use the host loop)");
+  if (opt->max_iterations < 0) return fail(NOS_ERR_INVALID_ARGUMENT, "max_iterations < 0");
+  nos_ctx* ctx = ds->ctx;
+  const Shard& sh = ds->shards[0];
+  DeviceSlot& slot = ctx->slots[sh.slot];
+  NOS_HIP_CHECK(hipSetDevice(slot.device));
+  const bool with_comm = ctx->comm != nullptr;
+  const bool step_in_launch = !with_comm && env_int("NOS_LM_FUSED", 1) != 0;
+  int window = opt->launches_in_flight > 0 ? opt->launches_in_flight : env_int("NOS_LM_WINDOW", 3);
+  window = std::max(1, std::min(window, kLogSlots - 2));
+
+  nos::LmInitArgs init{};
+  for (int k = 0; k < nR; ++k) init.R[k] = R[k];
+  for (int k = 0; k < nt; ++k) init.t[k] = t[k];
+  init.settings.max_iterations = opt->max_iterations;
+  init.settings.gradient_tolerance = opt->gradient_tolerance;
+  init.settings.parameter_tolerance = opt->parameter_tolerance;
+  init.dof = rq.n_out == 28 ? 6 : 3;
+  nos_host::LmState st;  // host mirror: what the log says after the last finished iteration
+  if (init.dof == 6)
+    nos_host::LmInit6(&st, init.R, init.t, opt->max_iterations);
+  else
+    nos_host::LmInit3(&st, init.R, init.t, opt->max_iterations);
+  hipLaunchKernelGGL(nos::lm_init_kernel, dim3(1), dim3(1), 0, slot.stream, slot.d_lm, init);
+  NOS_HIP_CHECK(hipGetLastError());
+
+  const unsigned long long base_seq = slot.seq;
+  unsigned long long* seq_dev = reinterpret_cast<unsigned long long*>(slot.h_out_dev + kSeqSlot);
+  int launched = 0, completed = 0;
+  auto launch_one = [&]() -> int {
+    double* entry = slot.h_log_dev + size_t(launched % kLogSlots) * nos::kLogEntryDoubles;
+    int rows = 0;
+    nos::FusedFinal fin{};
+    fin.counter = slot.counter;
+    fin.lm = slot.d_lm;
+    fin.seq = ++slot.seq;
+    if (step_in_launch) {
+      fin.out_host = entry;
+      fin.seq_host = seq_dev;
+      fin.lm_step = 1;
+      int rc = launch_assemble(ds, sh, rq, slot.partials, fin, slot.stream, &rows);
+      if (rc != NOS_OK) return rc;
+    } else {
+      fin.out_dev = slot.d_out;
+      int rc = launch_assemble(ds, sh, rq, slot.partials, fin, slot.stream, &rows);
+      if (rc != NOS_OK) return rc;
+      if (with_comm)
+        NOS_RCCL_CHECK(Rccl()->AllReduce(slot.d_out, slot.d_out, size_t(rq.n_out), ncclDouble, ncclSum, ctx->comm,
+                                         slot.stream));
+      if (rq.n_out == 28)
+        hipLaunchKernelGGL((nos::lm_step_kernel<28>), dim3(1), dim3(64), 0, slot.stream, slot.d_out, slot.d_lm, entry,
+                           seq_dev, fin.seq);
+      else
+        hipLaunchKernelGGL((nos::lm_step_kernel<10>), dim3(1), dim3(64), 0, slot.stream, slot.d_out, slot.d_lm, entry,
+                           seq_dev, fin.seq);
+      NOS_HIP_CHECK(hipGetLastError());
+    }
+    ++launched;
+    return NOS_OK;
+  };
+  int rc = NOS_OK;
+  while (rc == NOS_OK && launched < std::min(window, opt->max_iterations)) rc = launch_one();
+  while (rc == NOS_OK && completed < launched) {
+    rc = wait_for_sequence(slot, base_seq + completed + 1);
+    if (rc != NOS_OK) break;
+    if (!st.done) {
+      const double* e = slot.h_log + size_t(completed % kLogSlots) * nos::kLogEntryDoubles;
+      if (opt->cost_history != nullptr && completed < opt->max_iterations) opt->cost_history[completed] = e[rq.n_out - 1];
+      for (int k = 0; k < 9; ++k) st.R[k] = e[nos::kLogR + k];
+      for (int k = 0; k < 3; ++k) st.t[k] = e[nos::kLogT + k];
+      st.lambda = e[nos::kLogLambda];
+      st.previous_cost = e[nos::kLogPrevCost];
+      st.cost = e[nos::kLogCost];
+      st.iteration = int(e[nos::kLogIteration]);
+      st.done = int(e[nos::kLogDone]);
+      st.ok = int(e[nos::kLogOk]);
+#ifdef NOS_LM_TIMING
+      // wall_clock64 ticks (10 ns): start of the finishing workgroup, its ticket, step begin, step done, log written
+      fprintf(stderr, "[lm-timing] it %d: loop+ticket %.2f us, rows->sums %.2f us, step %.2f us, log %.2f us\n", completed,
+              (e[51] - e[50]) * 0.01, (e[52] - e[51]) * 0.01, (e[53] - e[52]) * 0.01, (e[54] - e[53]) * 0.01);
+      fprintf(stderr, "[lm-timing]        a block: prologue %.2f us, loads+math %.2f us, block reduce+store %.2f us\n",
+              e[56] * 0.01, e[57] * 0.01, e[58] * 0.01);
+#endif
+    }
+    ++completed;
+    if (!st.done && launched < opt->max_iterations) rc = launch_one();
+  }
+  if (rc != NOS_OK) {
+    (void)hipStreamSynchronize(slot.stream);  // leave nothing in flight behind an error
+    return rc;
+  }
+  for (int k = 0; k < nR; ++k) R[k] = st.R[k];
+  for (int k = 0; k < nt; ++k) t[k] = st.t[k];
+  if (report) {
+    report->iterations = st.iteration;
+    report->ok = st.ok;
+    report->launches = launched;
+    report->reserved = 0;
+    report->printed_cost = st.previous_cost;
+    report->last_cost = st.cost;
+    report->final_lambda = st.lambda;
+  }
   return NOS_OK;
 }
 
@@ -770,6 +884,11 @@ int nos_ctx_create(const int* device_ids, int n_devices, nos_ctx** out_ctx) {
     if (e == hipSuccess) e = hipHostMalloc(&s.h_out, sizeof(double) * 64, hipHostMallocMapped);
     if (e == hipSuccess) memset(s.h_out, 0, sizeof(double) * 64);
     if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&s.h_out_dev), s.h_out, 0);
+    if (e == hipSuccess) e = hipMalloc(&s.d_lm, sizeof(nos::LmDevice));
+    const size_t log_bytes = sizeof(double) * kLogSlots * nos::kLogEntryDoubles;
+    if (e == hipSuccess) e = hipHostMalloc(&s.h_log, log_bytes, hipHostMallocMapped);
+    if (e == hipSuccess) memset(s.h_log, 0, log_bytes);
+    if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&s.h_log_dev), s.h_log, 0);
     if (e == hipSuccess) e = hipMalloc(&s.counter, 2048);  // top ticket + 8 group tickets, 128 bytes apart
     if (e == hipSuccess) e = hipMemset(s.counter, 0, 2048);
     if (e == hipSuccess) e = hipEventCreate(&s.ev0);
@@ -806,6 +925,8 @@ int nos_ctx_destroy(nos_ctx* ctx) {
     if (s.d_out) (void)hipFree(s.d_out);
     if (s.h_out) (void)hipHostFree(s.h_out);
     if (s.counter) (void)hipFree(s.counter);
+    if (s.d_lm) (void)hipFree(s.d_lm);
+    if (s.h_log) (void)hipHostFree(s.h_log);
     if (s.ev0) (void)hipEventDestroy(s.ev0);
     if (s.ev1) (void)hipEventDestroy(s.ev1);
     if (s.ev2) (void)hipEventDestroy(s.ev2);
@@ -945,6 +1066,30 @@ int nos_reproj_accumulate_async(nos_dataset* ds, const double R[9], const double
   return accumulate_async(ds, rq, d_out28);
 }
 
+int nos_ndt6_solve(nos_dataset* ds, double R[9], double t[3], const nos_loss* loss, const nos_lm_options* options,
+                   nos_lm_report* report) {
+  Request rq;
+  int rc = build_request(6, ds, R, 9, t, 3, nullptr, 0.0, loss, &rq);
+  if (rc != NOS_OK) return rc;
+  return lm_solve(ds, rq, options, R, 9, t, 3, report);
+}
+
+int nos_ndt3_solve(nos_dataset* ds, double R2[4], double t2[2], const nos_loss* loss, const nos_lm_options* options,
+                   nos_lm_report* report) {
+  Request rq;
+  int rc = build_request(3, ds, R2, 4, t2, 2, nullptr, 0.0, loss, &rq);
+  if (rc != NOS_OK) return rc;
+  return lm_solve(ds, rq, options, R2, 4, t2, 2, report);
+}
+
+int nos_reproj_solve(nos_dataset* ds, double R[9], double t[3], const double intr[4], const nos_loss* loss,
+                     double min_depth, const nos_lm_options* options, nos_lm_report* report) {
+  Request rq;
+  int rc = build_request(2, ds, R, 9, t, 3, intr, min_depth, loss, &rq);
+  if (rc != NOS_OK) return rc;
+  return lm_solve(ds, rq, options, R, 9, t, 3, report);
+}
+
 int nos_ndt6_time_kernel(nos_dataset* ds, const double R[9], const double t[3], const nos_loss* loss, int repeats,
                          double* kernel_ms, double* total_ms) {
   Request rq;
@@ -1012,10 +1157,18 @@ int nos_ctx_comm_allreduce(nos_ctx* ctx, double* values, int count) {
 }
 
 int nos_ctx_profile_begin(nos_ctx* ctx, int max_launches, int sample_every) {
-  if (!ctx || max_launches < 1 || max_launches > (1 << 20) || sample_every < 1)
+  if (!ctx || max_launches < 1 || max_launches > (1 << 20) || sample_every < 0)
     return fail(NOS_ERR_INVALID_ARGUMENT, "bad profile request");
   for (DeviceSlot& s : ctx->slots) {
     NOS_HIP_CHECK(hipSetDevice(s.device));
+    if (sample_every == 0) {  // bracket form
+      s.prof_used = 0;
+      s.prof_every = 0;
+      s.prof_launches = 0;
+      s.prof_on = true;
+      NOS_HIP_CHECK(hipEventRecord(s.ev0, s.stream));
+      continue;
+    }
     while (s.prof_events.size() < size_t(max_launches) * 2) {
       hipEvent_t e = nullptr;
       NOS_HIP_CHECK(hipEventCreate(&e));
@@ -1034,8 +1187,24 @@ int nos_ctx_profile_end(nos_ctx* ctx, int* n_launches, double* mean_ms, double* 
   int count = 0;
   double sum = 0.0, lo = 1e300, hi = 0.0;
   for (DeviceSlot& s : ctx->slots) {
+    const bool bracket = s.prof_on && s.prof_every == 0;
     s.prof_on = false;
     NOS_HIP_CHECK(hipSetDevice(s.device));
+    if (bracket) {
+      NOS_HIP_CHECK(hipEventRecord(s.ev1, s.stream));
+      NOS_HIP_CHECK(hipEventSynchronize(s.ev1));
+      float ms = 0.f;
+      NOS_HIP_CHECK(hipEventElapsedTime(&ms, s.ev0, s.ev1));
+      if (s.prof_launches > 0) {
+        const double per = double(ms) / double(s.prof_launches);
+        sum += per * double(s.prof_launches);
+        lo = std::min(lo, per);
+        hi = std::max(hi, per);
+        count += int(s.prof_launches);
+      }
+      s.prof_every = 1;
+      continue;
+    }
     NOS_HIP_CHECK(hipStreamSynchronize(s.stream));
     for (size_t i = 0; i + 1 < s.prof_used; i += 2) {
       float ms = 0.f;

@@ -58,6 +58,7 @@ enum DatasetKind { kKindNdt = 1, kKindReproj = 2, kKindNdtIndexed = 3 };
 
 constexpr int kMaxPartialRows = 8192;  // upper bound on grid size of the assemble kernel
 constexpr int kMaxOut = 28;
+constexpr int kLogSlots = 64;          // ring of loop log entries; bounds the number of launches in flight
 
 struct DeviceSlot {
   int device = 0;
@@ -70,6 +71,9 @@ struct DeviceSlot {
   double* h_out_dev = nullptr;     // device-side address of h_out
   unsigned int* counter = nullptr; // device ticket word of the in-launch final reduce (kept at 0 between launches)
   unsigned long long seq = 0;      // last sequence value handed to a fused launch
+  nos::LmDevice* d_lm = nullptr;   // device-resident loop state (nos_*_solve)
+  double* h_log = nullptr;         // pinned, device-mapped ring of per-iteration log entries [kLogSlots][kLogEntryDoubles]
+  double* h_log_dev = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
   // per-launch kernel timing (nos_ctx_profile_begin/_end): event pairs recorded on the
   // launch stream around every assemble kernel while profiling is on

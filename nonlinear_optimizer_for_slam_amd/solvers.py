@@ -51,12 +51,18 @@ def _planes_arg(planes, count):
 
 
 class _HipSolverBase:
-    def __init__(self, device_ids=(0,), dtype="f64", print_cost_line=False):
+    def __init__(self, device_ids=(0,), dtype="f64", print_cost_line=False, device_loop=True):
+        """device_loop: run the whole LM loop device-resident (nos_*_solve, the default on single-device contexts);
+        False = the host loop around nos_*_accumulate."""
         self._loss = None
+        self.device_loop = device_loop
         self.device_ids = tuple(device_ids)
         self.dtype = dtype
         self.print_cost_line = print_cost_line
         self.report = None
+
+    def _flags(self):
+        return int(bool(self.print_cost_line)) | (0 if self.device_loop else 2)
 
     def SetLossFunction(self, loss):
         """loss: None | ("exponential", c1, c2) | ("huber", threshold)."""
@@ -82,7 +88,7 @@ class MahalanobisDistanceMinimizerHip(_HipSolverBase):
             ctypes.c_double(l.a), ctypes.c_double(l.b), ctypes.c_int(options.max_iterations),
             ctypes.c_double(options.gradient_tolerance), ctypes.c_double(options.parameter_tolerance),
             ctypes.c_int(_lib.NOS_F32 if self.dtype == "f32" else _lib.NOS_F64), ids, len(self.device_ids),
-            ctypes.c_int(int(self.print_cost_line)), ctypes.c_int(repeat_solves),
+            ctypes.c_int(self._flags()), ctypes.c_int(repeat_solves),
             t.ctypes.data_as(_lib.c_double_p), R.ctypes.data_as(_lib.c_double_p),
             rep.ctypes.data_as(_lib.c_double_p))
         self.report = SolveReport(rep)
@@ -101,7 +107,7 @@ class MahalanobisDistanceMinimizerHip(_HipSolverBase):
         ok = host_lib().nos_host_ndt_solve_dataset(
             ctypes.c_int(self._dof), dataset._h, ctypes.c_int(l.kind), ctypes.c_double(l.a), ctypes.c_double(l.b),
             ctypes.c_int(options.max_iterations), ctypes.c_double(options.gradient_tolerance),
-            ctypes.c_double(options.parameter_tolerance), ctypes.c_int(int(self.print_cost_line)),
+            ctypes.c_double(options.parameter_tolerance), ctypes.c_int(self._flags()),
             t.ctypes.data_as(_lib.c_double_p), R.ctypes.data_as(_lib.c_double_p), rep.ctypes.data_as(_lib.c_double_p))
         self.report = SolveReport(rep)
         if ok:
@@ -132,7 +138,7 @@ class ReprojectionErrorMinimizerHip(_HipSolverBase):
             ctypes.c_double(l.a), ctypes.c_double(l.b), ctypes.c_int(options.max_iterations),
             ctypes.c_double(options.gradient_tolerance), ctypes.c_double(options.parameter_tolerance),
             ctypes.c_int(_lib.NOS_F32 if self.dtype == "f32" else _lib.NOS_F64), ids, len(self.device_ids),
-            ctypes.c_int(int(self.print_cost_line)), t.ctypes.data_as(_lib.c_double_p),
+            ctypes.c_int(self._flags()), t.ctypes.data_as(_lib.c_double_p),
             R.ctypes.data_as(_lib.c_double_p), rep.ctypes.data_as(_lib.c_double_p))
         self.report = SolveReport(rep)
         if ok:

@@ -1,0 +1,214 @@
+"""The device-resident Levenberg-Marquardt loop (nos_ndt6_solve / nos_ndt3_solve / nos_reproj_solve) against the
+oracle's restatement of the reference's Solve() loops (oracle/nos_oracle.c, MDM/…_analytic_simd.cc:30-108,
+MDM/…_analytic_3dof.cc:17-108, REM/…_analytic.cc:15-105) and against the host loop around nos_*_accumulate.
+
+Tolerances: the loop body is the same source on host and device (csrc/host/nos_lm.hpp); device fp64 differs from the
+host only by fused multiply-adds, so poses agree to 1e-9 and iteration counts exactly (north star: 1e-6).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from tests import helpers
+from nonlinear_optimizer_for_slam_amd import solvers, synth
+from nonlinear_optimizer_for_slam_amd.api import Context, NdtDataset, NdtIndexedDataset, ReprojDataset
+
+pytestmark = pytest.mark.gpu
+
+EXP = ("exponential", 1.0, 1.0)
+
+
+@pytest.mark.parametrize("loss", [EXP, None, ("huber", 0.7)])
+@pytest.mark.parametrize("dtype", ["f64"])
+def test_ndt6_device_loop_matches_oracle(ctx, oracle, loss, dtype):
+    """BASELINE.json configs[0] shape: 100k points / 5k voxels, default Options."""
+    planes = synth.ndt_planes(100_000, 5000)
+    want = oracle.ndt6_solve(planes, np.zeros(3), np.eye(3), loss=loss, max_iterations=100, linear_solver=1)
+    ds = NdtDataset.from_planes(ctx, planes, dtype)
+    R, t, rep = ds.solve6(np.eye(3), np.zeros(3), loss, max_iterations=100)
+    assert rep["ok"]
+    assert rep["iterations"] == want["iterations"]
+    assert rep["printed_cost"] == pytest.approx(want["printed_cost"], rel=1e-9)
+    assert rep["last_cost"] == pytest.approx(want["last_cost"], rel=1e-9)
+    assert rep["final_lambda"] == pytest.approx(want["final_lambda"], rel=1e-12)
+    dt, dq = helpers.pose_delta(R.reshape(3, 3), t, want["R"], want["t"])
+    assert dt < 1e-6 and dq < 1e-6, (dt, dq)   # north-star tolerance
+    assert dt < 1e-9 and dq < 1e-9, (dt, dq)   # what fp64 delivers
+    # executed iterations = exit index + 1 when a convergence test fired
+    assert len(rep["cost_history"]) in (rep["iterations"], rep["iterations"] + 1)
+    assert rep["launches"] >= len(rep["cost_history"])
+    ds.close()
+
+
+def test_ndt6_device_loop_f32_tracks_fp64_oracle(ctx, oracle):
+    planes = synth.ndt_planes(100_000, 5000)
+    want = oracle.ndt6_solve(planes, np.zeros(3), np.eye(3), loss=EXP, max_iterations=100, linear_solver=1)
+    ds = NdtDataset.from_planes(ctx, planes, "f32")
+    R, t, rep = ds.solve6(np.eye(3), np.zeros(3), EXP, max_iterations=100)
+    dt, dq = helpers.pose_delta(R.reshape(3, 3), t, want["R"], want["t"])
+    assert rep["ok"] and dt < 2e-4 and dq < 2e-4, (dt, dq)
+    ds.close()
+
+
+def test_device_loop_is_independent_of_launches_in_flight_and_step_placement(ctx):
+    """Same bits whether 1, 3 or 16 launches are kept queued, and whether the loop body runs in the finishing
+    workgroup of the assemble launch or in the stand-alone one-wave step kernel."""
+    planes = synth.ndt_planes(70_000, 3500)
+    ds = NdtDataset.from_planes(ctx, planes, "f64")
+    ref = ds.solve6(np.eye(3), np.zeros(3), EXP, max_iterations=50, launches_in_flight=1)
+    for window in (3, 16):
+        got = ds.solve6(np.eye(3), np.zeros(3), EXP, max_iterations=50, launches_in_flight=window)
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+        assert got[2]["iterations"] == ref[2]["iterations"]
+        assert np.array_equal(got[2]["cost_history"], ref[2]["cost_history"])
+    os.environ["NOS_LM_FUSED"] = "0"
+    try:
+        got = ds.solve6(np.eye(3), np.zeros(3), EXP, max_iterations=50)
+    finally:
+        del os.environ["NOS_LM_FUSED"]
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+    assert np.array_equal(got[2]["cost_history"], ref[2]["cost_history"])
+    ds.close()
+
+
+def test_device_loop_costs_equal_host_loop_costs(ctx):
+    """Iteration by iteration: the device loop's cost history against the host loop that calls nos_ndt6_accumulate
+    (same kernel, same sums) — the two may only differ through the pose update's last bits."""
+    planes = synth.ndt_planes(50_000, 2500)
+    ds = NdtDataset.from_planes(ctx, planes, "f64")
+    _, _, rep = ds.solve6(np.eye(3), np.zeros(3), EXP, max_iterations=30)
+    solver = solvers.MahalanobisDistanceMinimizerHip(device_loop=False)
+    solver.SetLossFunction(EXP)
+    pose = solvers.Pose()
+    opt = solvers.Options()
+    opt.max_iterations = 30
+    assert solver.SolveDataset(opt, ds, pose)
+    assert solver.report.iterations == rep["iterations"]
+    assert solver.report.printed_cost == pytest.approx(rep["printed_cost"], rel=1e-10)
+    ds.close()
+
+
+def test_ndt3_device_loop_matches_oracle(ctx, oracle):
+    planes = synth.ndt_planes(60_000, 3000)
+    want = oracle.ndt3_solve(planes, np.zeros(3), np.eye(3), loss=EXP, max_iterations=100)
+    ds = NdtDataset.from_planes(ctx, planes, "f64")
+    R2, t2, rep = ds.solve3(np.eye(2), np.zeros(2), EXP, max_iterations=100)
+    assert rep["ok"] and rep["iterations"] == want["iterations"]
+    np.testing.assert_allclose(t2, want["t"][:2], atol=1e-9)
+    np.testing.assert_allclose(R2.reshape(2, 2), want["R"][:2, :2], atol=1e-9)
+    assert rep["printed_cost"] == pytest.approx(want["printed_cost"], rel=1e-9)
+    ds.close()
+
+
+def test_reproj_device_loop_huber_matches_oracle(ctx, oracle):
+    """BASELINE.json configs[2] shape (scaled to 200k): Huber loss, noisy pixels, 5 % outliers."""
+    planes = synth.reproj_planes(200_000)
+    loss = ("huber", synth.REPROJ_HUBER_THRESHOLD)
+    want = oracle.reproj_solve(planes, synth.REPROJ_INTR4, np.zeros(3), np.eye(3), loss=loss, max_iterations=100,
+                               linear_solver=1)
+    ds = ReprojDataset.from_planes(ctx, planes, "f64")
+    R, t, rep = ds.solve(np.eye(3), np.zeros(3), synth.REPROJ_INTR4, loss, max_iterations=100)
+    assert rep["ok"] and rep["iterations"] == want["iterations"]
+    dt, dq = helpers.pose_delta(R.reshape(3, 3), t, want["R"], want["t"])
+    assert dt < 1e-8 and dq < 1e-8, (dt, dq)
+    ds.close()
+
+
+def test_reprojection_known_answer_through_the_device_loop(ctx):
+    """End-to-end golden of the reference (results/reproj_amd64.txt:5,8): from identity with
+    ExponentialLossFunction(1,1) and default Options → `COST: 2.33228e-11, iter: 6` and the true pose."""
+    planes, intr, Rt, tt = helpers.reference_reprojection_scene()
+    ds = ReprojDataset.from_planes(ctx, planes, "f64")
+    intr4 = np.array([1.0 / intr[0], 1.0 / intr[1], intr[2], intr[3]])   # (fx, fy, cx, cy) → kernel form
+    opt = solvers.Options()
+    R, t, rep = ds.solve(np.eye(3), np.zeros(3), intr4, EXP, max_iterations=opt.max_iterations,
+                         gradient_tolerance=opt.gradient_tolerance, parameter_tolerance=opt.parameter_tolerance)
+    assert rep["iterations"] == 6
+    assert "%.5g" % rep["printed_cost"] == "2.3323e-11"
+    pose = solvers.Pose(R.reshape(3, 3), t)
+    inv = pose.inverse()
+    np.testing.assert_allclose(inv.t, tt, atol=5e-7)
+    np.testing.assert_allclose(inv.R, Rt, atol=1e-7)
+    ds.close()
+
+
+@pytest.mark.parametrize("max_iterations", [0, 1, 2])
+def test_iteration_budget_edges(ctx, oracle, max_iterations):
+    planes = synth.ndt_planes(20_000, 1000)
+    want = oracle.ndt6_solve(planes, np.zeros(3), np.eye(3), loss=EXP, max_iterations=max_iterations, linear_solver=1)
+    ds = NdtDataset.from_planes(ctx, planes, "f64")
+    R, t, rep = ds.solve6(np.eye(3), np.zeros(3), EXP, max_iterations=max_iterations)
+    assert rep["iterations"] == want["iterations"] == max_iterations
+    assert rep["launches"] == max_iterations
+    dt, dq = helpers.pose_delta(R.reshape(3, 3), t, want["R"], want["t"])
+    assert dt < 1e-12 and dq < 1e-12
+    if max_iterations == 0:
+        assert rep["printed_cost"] == np.finfo(np.float64).max   # the reference prints DBL_MAX here
+    ds.close()
+
+
+def test_empty_dataset_reports_failed_solve_and_keeps_the_pose(ctx):
+    """H = 0: the damped LDLᵀ meets a zero pivot.  (Eigen's ldlt() would hand NaNs to the pose; the host loop of this
+    repository reports failure instead, and so does the device loop.)"""
+    ds = NdtDataset.from_planes(ctx, np.zeros((15, 0)), "f64")
+    R0 = helpers.rot_xyz(0.1, -0.2, 0.3)
+    R, t, rep = ds.solve6(R0, [1.0, 2.0, 3.0], EXP, max_iterations=10)
+    assert not rep["ok"] and rep["iterations"] == 0
+    np.testing.assert_allclose(R.reshape(3, 3), R0, atol=1e-15)
+    np.testing.assert_array_equal(t, [1.0, 2.0, 3.0])
+    ds.close()
+
+
+def test_indexed_dataset_device_loop_equals_flat_dataset_loop(ctx):
+    planes = synth.ndt_planes(40_000, 2000)
+    # voxel table + index view of the same correspondences: every point has exactly one voxel record
+    means = planes[3:6].T.copy()
+    sq = planes[6:15].T.reshape(-1, 3, 3).copy()
+    uniq, inv = np.unique(np.concatenate([means, sq.reshape(-1, 9)], axis=1), axis=0, return_inverse=True)
+    flat = NdtDataset.from_planes(ctx, planes, "f64")
+    idx = NdtIndexedDataset.from_arrays(ctx, planes[0:3].copy(), inv.reshape(1, -1).astype(np.int32), uniq[:, :3].copy(),
+                                        uniq[:, 3:].reshape(-1, 3, 3).copy(), "f64")
+    a = flat.solve6(np.eye(3), np.zeros(3), EXP, max_iterations=40)
+    b = idx.solve6(np.eye(3), np.zeros(3), EXP, max_iterations=40)
+    assert a[2]["iterations"] == b[2]["iterations"]
+    dt, dq = helpers.pose_delta(a[0].reshape(3, 3), a[1], b[0].reshape(3, 3), b[1])
+    assert dt < 1e-9 and dq < 1e-9
+    flat.close()
+    idx.close()
+
+
+def test_device_loop_behind_a_single_rank_communicator(oracle):
+    """One process per GPU: launch → RCCL all-reduce → one-wave step kernel, all on the stream."""
+    from nonlinear_optimizer_for_slam_amd import _lib
+    from nonlinear_optimizer_for_slam_amd.api import new_unique_id
+    planes = synth.ndt_planes(65_000, 3000)
+    c = Context((0,))
+    ds = NdtDataset.from_planes(c, planes, "f64")
+    ref = ds.solve6(np.eye(3), np.zeros(3), EXP, max_iterations=40)
+    try:
+        c.comm_init(1, 0, new_unique_id())
+    except _lib.NosError as exc:
+        ds.close()
+        c.close()
+        pytest.skip("RCCL could not create a 1-rank communicator on this box: %s" % exc)
+    got = ds.solve6(np.eye(3), np.zeros(3), EXP, max_iterations=40)
+    assert got[2]["iterations"] == ref[2]["iterations"]
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+    ds.close()
+    c.close()
+
+
+def test_cpp_classes_use_the_device_loop_by_default_and_agree_with_the_host_loop():
+    planes = synth.ndt_planes(80_000, 4000)
+    res = {}
+    for device_loop in (True, False):
+        solver = solvers.MahalanobisDistanceMinimizerHip(device_loop=device_loop)
+        solver.SetLossFunction(EXP)
+        pose = solvers.Pose()
+        assert solver.Solve(solvers.Options(), planes, pose)
+        res[device_loop] = (pose.R.copy(), pose.t.copy(), solver.report.iterations, solver.report.printed_cost)
+    assert res[True][2] == res[False][2]
+    dt, dq = helpers.pose_delta(res[True][0], res[True][1], res[False][0], res[False][1])
+    assert dt < 1e-10 and dq < 1e-10
+    assert res[True][3] == pytest.approx(res[False][3], rel=1e-10)

@@ -41,11 +41,17 @@ def ndt_case(name, n, voxels, dtype, loss):
                                    pR.ctypes.data_as(_lib.c_double_p), rep.ctypes.data_as(_lib.c_double_p))
 
     it = lm_iter_ms(run)
+
+    def run_dev(k):
+        ds.solve6(np.eye(3), np.zeros(3), loss, max_iterations=k, gradient_tolerance=0.0, parameter_tolerance=0.0)
+
+    it_dev = lm_iter_ms(run_dev)
     b = ds.stream_bytes
     print(json.dumps({"config": name, "n": n, "dtype": dtype, "loss": loss[0] if loss else "none",
                       "ndt6_kernel_ms": k6, "ndt6_kernel_GBps": b / k6 / 1e6, "ndt6_fused_ms": tot6,
                       "ndt3_kernel_ms": k3, "ndt3_kernel_GBps": b / k3 / 1e6,
-                      "ndt6_lm_iteration_ms": it, "ndt6_corr_per_s": n / it * 1e3}), flush=True)
+                      "ndt6_lm_iteration_ms": it, "ndt6_corr_per_s": n / it * 1e3,
+                      "ndt6_device_loop_iteration_ms": it_dev, "ndt6_device_loop_corr_per_s": n / it_dev * 1e3}), flush=True)
     ds.close()
 
 
@@ -65,10 +71,17 @@ def reproj_case(name, n, dtype, loss):
                                      pR.ctypes.data_as(_lib.c_double_p), rep.ctypes.data_as(_lib.c_double_p))
 
     it = lm_iter_ms(run, 500, 50)
+
+    def run_dev(kk):
+        ds.solve(np.eye(3), np.zeros(3), synth.REPROJ_INTR4, loss, max_iterations=kk, gradient_tolerance=0.0,
+                 parameter_tolerance=0.0)
+
+    it_dev = lm_iter_ms(run_dev, 500, 50)
     b = ds.stream_bytes
     print(json.dumps({"config": name, "n": n, "dtype": dtype, "loss": loss[0] if loss else "none",
                       "reproj_kernel_ms": k, "reproj_kernel_GBps": b / k / 1e6, "reproj_fused_ms": tot,
-                      "reproj_lm_iteration_ms": it, "reproj_corr_per_s": n / it * 1e3}), flush=True)
+                      "reproj_lm_iteration_ms": it, "reproj_corr_per_s": n / it * 1e3,
+                      "reproj_device_loop_iteration_ms": it_dev, "reproj_device_loop_corr_per_s": n / it_dev * 1e3}), flush=True)
     ds.close()
 
 
