@@ -180,6 +180,14 @@ size_t nos_ndt_map_size(const nos_ndt_map* map); /* valid voxels */
 int nos_scan_create(nos_ctx* ctx, size_t n_points, const double* points_xyz, nos_scan** out_scan);
 int nos_scan_destroy(nos_scan* scan);
 size_t nos_scan_size(const nos_scan* scan);
+/* Optional, once per scan: reorder the points by grid cell of edge cell_edge (in the scan's own frame) so that
+ * the points one wavefront of the matcher handles are spatial neighbours (a rigid pose keeps them so).  The
+ * matcher's output slots then follow the new order; nos_scan_order gives order[j] = index, in the array handed
+ * to nos_scan_create, of the point now stored at position j (identity if the scan was never sorted).  The
+ * solver does not care about correspondence order (sums), the reference's harness pushes them in scan order
+ * (MDM/tests/simple_optimization_test.cc:296-342). */
+int nos_scan_sort_by_cell(nos_scan* scan, double cell_edge);
+int nos_scan_order(const nos_scan* scan, uint32_t* order_out);
 int nos_ndt_match(nos_ndt_map* map, nos_scan* scan, const double R[9], const double t[3],
                   int max_neighbors, int dtype, nos_dataset** out_ds, size_t* n_matches);
 

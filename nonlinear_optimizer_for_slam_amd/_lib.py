@@ -29,7 +29,7 @@ C_ABI_SYMBOLS = (
     "nos_ndt_dataset_create_from_device", "nos_reproj_dataset_create_from_device",
     "nos_ndt_dataset_create_from_records", "nos_reproj_dataset_create_from_records",
     "nos_dataset_download", "nos_ndt_map_create", "nos_ndt_map_destroy", "nos_ndt_map_size", "nos_scan_create",
-    "nos_scan_destroy", "nos_scan_size", "nos_ndt_match", "nos_ndt_indexed_dataset_create", "nos_ndt_match_indexed", "nos_ndt_map_build", "nos_map_stats_size",
+    "nos_scan_destroy", "nos_scan_size", "nos_scan_sort_by_cell", "nos_scan_order", "nos_ndt_match", "nos_ndt_indexed_dataset_create", "nos_ndt_match_indexed", "nos_ndt_map_build", "nos_map_stats_size",
     "nos_map_stats_get", "nos_map_stats_destroy", "nos_pgo_create", "nos_pgo_destroy", "nos_pgo_num_unknowns",
     "nos_pgo_linearize", "nos_pgo_solve", "nos_pgo_retract", "nos_pgo_get_state", "nos_pgo_get_vector",
     "nos_pgo_matvec", "nos_dataset_destroy", "nos_dataset_size", "nos_dataset_dtype", "nos_dataset_stream_bytes",
@@ -114,6 +114,8 @@ def _declare(lib):
     lib.nos_scan_destroy.argtypes = [vp]
     lib.nos_scan_size.argtypes = [vp]
     lib.nos_scan_size.restype = sz
+    lib.nos_scan_sort_by_cell.argtypes = [vp, ctypes.c_double]
+    lib.nos_scan_order.argtypes = [vp, ctypes.POINTER(ctypes.c_uint32)]
     lib.nos_ndt_match.argtypes = [vp, vp, dp, dp, i, i, c_void_pp, ctypes.POINTER(sz)]
     lib.nos_ndt_indexed_dataset_create.argtypes = [vp, sz, ctypes.POINTER(dp), i, ctypes.POINTER(ctypes.POINTER(ctypes.c_int32)),
                                                    sz, dp, dp, i, i, c_void_pp]

@@ -484,7 +484,9 @@ class NdtMap:
 class Scan:
     """Device-resident scan points in the sensor's local frame (nos_scan): points [n,3]."""
 
-    def __init__(self, ctx, points):
+    def __init__(self, ctx, points, sort_cell=None):
+        """sort_cell: if set, reorder the points by grid cell of that edge (nos_scan_sort_by_cell) — faster matching
+        for scans whose points do not arrive in spatial order; `order` then maps positions to input indices."""
         self._ctx = ctx
         self._lib = ctx._lib
         pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
@@ -492,6 +494,18 @@ class Scan:
         check(self._lib.nos_scan_create(ctx.handle, pts.shape[0], _dp(pts), ctypes.byref(h)), "nos_scan_create")
         self._h = h
         ctx._adopt(self)
+        if sort_cell is not None:
+            self.sort_by_cell(sort_cell)
+
+    def sort_by_cell(self, cell_edge):
+        check(self._lib.nos_scan_sort_by_cell(self._h, ctypes.c_double(cell_edge)), "nos_scan_sort_by_cell")
+
+    @property
+    def order(self):
+        """order[j] = index (in the array given to the constructor) of the point stored at position j."""
+        out = np.zeros(len(self), dtype=np.uint32)
+        check(self._lib.nos_scan_order(self._h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))), "nos_scan_order")
+        return out
 
     def __len__(self):
         return int(self._lib.nos_scan_size(self._h))

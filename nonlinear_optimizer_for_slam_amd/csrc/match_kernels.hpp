@@ -35,6 +35,15 @@ struct MapView {
   uint32_t table_mask;       // table size - 1 (power of two)
   double inv_cell;           // 1 / cell edge
   double radius_sq;
+  // Dense form of the same grid (set when the map's bounding box is small enough, which it is for every
+  // scene the reference handles): cells in lexicographic (x, y, z) order — the order the voxel records are
+  // stored in — with `dense_begin[c]` = number of records in cells before c.  The three z-neighbours of a
+  // column are consecutive cells, so their records are ONE contiguous run [begin[c-1], begin[c+2]): a point
+  // inspects 9 runs (2 loads each) instead of probing a hash table 27 times.
+  const uint32_t* dense_begin;  // [nx*ny*nz + 1], null = hash table only
+  const double* record;         // [V][4] = mean x, y, z, original id (bit pattern) — one 32-byte candidate record
+  int64_t ox, oy, oz;           // cell coordinates of dense cell (0,0,0)
+  int32_t nx, ny, nz;
 };
 
 __host__ __device__ __forceinline__ uint64_t pack_cell(int64_t ix, int64_t iy, int64_t iz) {
@@ -57,6 +66,93 @@ struct PosePod {
   double t[3];
 };
 
+struct TwoNearest {
+  double d[2];
+  uint32_t j[2];   // position in the map's cell-ordered arrays, 0xFFFFFFFF = none
+  uint32_t id[2];  // original voxel id (tie-break)
+  __device__ __forceinline__ void init() {
+    d[0] = d[1] = 1e300;
+    j[0] = j[1] = id[0] = id[1] = 0xFFFFFFFFu;
+  }
+  // keep the two smallest (distance, original id) pairs, nearest first
+  __device__ __forceinline__ void offer(double dist, uint32_t pos, uint32_t orig) {
+    if (dist < d[0] || (dist == d[0] && orig < id[0])) {
+      d[1] = d[0];
+      j[1] = j[0];
+      id[1] = id[0];
+      d[0] = dist;
+      j[0] = pos;
+      id[0] = orig;
+    } else if (dist < d[1] || (dist == d[1] && orig < id[1])) {
+      d[1] = dist;
+      j[1] = pos;
+      id[1] = orig;
+    }
+  }
+};
+
+// The (up to) two nearest valid voxel means within the radius of the world point q — FLANN radiusSearch with
+// max_neighbors = 2 on squared distances, ties broken by original voxel id.  Same result from both grid forms.
+__device__ __forceinline__ void find_two_nearest(const MapView& map, double qx, double qy, double qz, TwoNearest& best) {
+  best.init();
+  const int64_t cx = int64_t(floor(qx * map.inv_cell));
+  const int64_t cy = int64_t(floor(qy * map.inv_cell));
+  const int64_t cz = int64_t(floor(qz * map.inv_cell));
+  if (map.dense_begin != nullptr) {
+    const int64_t rx = cx - map.ox, ry = cy - map.oy, rz = cz - map.oz;
+    const int64_t z0 = rz - 1 < 0 ? 0 : rz - 1;
+    const int64_t z1 = rz + 1 > map.nz - 1 ? map.nz - 1 : rz + 1;
+    if (z0 > z1) return;
+    using V2 = double __attribute__((ext_vector_type(2)));
+    const V2* rec = reinterpret_cast<const V2*>(map.record);
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) {
+      const int64_t xx = rx + dx;
+      if (xx < 0 || xx >= map.nx) continue;
+#pragma unroll
+      for (int dy = -1; dy <= 1; ++dy) {
+        const int64_t yy = ry + dy;
+        if (yy < 0 || yy >= map.ny) continue;
+        const int64_t col = (xx * map.ny + yy) * map.nz;
+        const uint32_t b = map.dense_begin[col + z0];
+        const uint32_t e = map.dense_begin[col + z1 + 1];
+        for (uint32_t j = b; j < e; ++j) {
+          const V2 m01 = rec[2 * size_t(j)];
+          const V2 m23 = rec[2 * size_t(j) + 1];
+          const double ex = qx - m01[0], ey = qy - m01[1], ez = qz - m23[0];
+          const double dist = ex * ex + ey * ey + ez * ez;
+          if (dist < map.radius_sq) best.offer(dist, j, uint32_t(__double_as_longlong(m23[1])));
+        }
+      }
+    }
+    return;
+  }
+  for (int dz = -1; dz <= 1; ++dz)
+    for (int dy = -1; dy <= 1; ++dy)
+      for (int dx = -1; dx <= 1; ++dx) {
+        const uint64_t key = pack_cell(cx + dx, cy + dy, cz + dz);
+        uint32_t h = hash_cell(key) & map.table_mask;
+        uint32_t start = 0, count = 0;
+        for (uint32_t probe = 0; probe <= map.table_mask; ++probe) {  // bounded: table is never full
+          const uint64_t k = map.cell_key[h];
+          if (k == key) {
+            start = map.cell_start[h];
+            count = map.cell_count[h];
+            break;
+          }
+          if (k == kEmptyCell) break;
+          h = (h + 1) & map.table_mask;
+        }
+        for (uint32_t j = start; j < start + count; ++j) {
+          const double ex = qx - map.mean[3 * size_t(j)];
+          const double ey = qy - map.mean[3 * size_t(j) + 1];
+          const double ez = qz - map.mean[3 * size_t(j) + 2];
+          const double dist = ex * ex + ey * ey + ez * ez;
+          if (dist < map.radius_sq) best.offer(dist, j, map.orig_id[j]);
+        }
+      }
+}
+
 // One thread per scan point.  points: 3 planes of n doubles (local frame).
 template <typename DST>
 __global__ __launch_bounds__(256) void match_kernel(MapView map, const double* __restrict__ px,
@@ -72,50 +168,9 @@ __global__ __launch_bounds__(256) void match_kernel(MapView map, const double* _
     const double qx = pose.R[0] * x + pose.R[1] * y + pose.R[2] * z + pose.t[0];
     const double qy = pose.R[3] * x + pose.R[4] * y + pose.R[5] * z + pose.t[1];
     const double qz = pose.R[6] * x + pose.R[7] * y + pose.R[8] * z + pose.t[2];
-    const int64_t cx = int64_t(floor(qx * map.inv_cell));
-    const int64_t cy = int64_t(floor(qy * map.inv_cell));
-    const int64_t cz = int64_t(floor(qz * map.inv_cell));
-    double best_d[2] = {1e300, 1e300};
-    uint32_t best_j[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
-    uint32_t best_id[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
-    for (int dz = -1; dz <= 1; ++dz)
-      for (int dy = -1; dy <= 1; ++dy)
-        for (int dx = -1; dx <= 1; ++dx) {
-          const uint64_t key = pack_cell(cx + dx, cy + dy, cz + dz);
-          uint32_t h = hash_cell(key) & map.table_mask;
-          uint32_t start = 0, count = 0;
-          for (uint32_t probe = 0; probe <= map.table_mask; ++probe) {  // bounded: table is never full
-            const uint64_t k = map.cell_key[h];
-            if (k == key) {
-              start = map.cell_start[h];
-              count = map.cell_count[h];
-              break;
-            }
-            if (k == kEmptyCell) break;
-            h = (h + 1) & map.table_mask;
-          }
-          for (uint32_t j = start; j < start + count; ++j) {
-            const double ex = qx - map.mean[3 * size_t(j)];
-            const double ey = qy - map.mean[3 * size_t(j) + 1];
-            const double ez = qz - map.mean[3 * size_t(j) + 2];
-            const double d = ex * ex + ey * ey + ez * ez;
-            if (!(d < map.radius_sq)) continue;
-            const uint32_t id = map.orig_id[j];
-            // keep the two smallest (distance, original id) pairs, nearest first
-            if (d < best_d[0] || (d == best_d[0] && id < best_id[0])) {
-              best_d[1] = best_d[0];
-              best_j[1] = best_j[0];
-              best_id[1] = best_id[0];
-              best_d[0] = d;
-              best_j[0] = j;
-              best_id[0] = id;
-            } else if (d < best_d[1] || (d == best_d[1] && id < best_id[1])) {
-              best_d[1] = d;
-              best_j[1] = j;
-              best_id[1] = id;
-            }
-          }
-        }
+    TwoNearest best;
+    find_two_nearest(map, qx, qy, qz, best);
+    const uint32_t (&best_j)[2] = best.j;
     // two consecutive slots 2i, 2i+1 → one 2-wide store per field
     const uint64_t i0 = 2 * i;
     const uint64_t off = (i0 >> L.tile_shift) * L.tile_stride + (i0 & L.tile_mask);

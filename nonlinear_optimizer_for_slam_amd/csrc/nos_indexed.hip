@@ -199,46 +199,9 @@ __global__ __launch_bounds__(256) void match_index_kernel(nos::MapView map, cons
     const double qx = pose.R[0] * x + pose.R[1] * y + pose.R[2] * z + pose.t[0];
     const double qy = pose.R[3] * x + pose.R[4] * y + pose.R[5] * z + pose.t[1];
     const double qz = pose.R[6] * x + pose.R[7] * y + pose.R[8] * z + pose.t[2];
-    const int64_t cx = int64_t(floor(qx * map.inv_cell)), cy = int64_t(floor(qy * map.inv_cell)),
-                  cz = int64_t(floor(qz * map.inv_cell));
-    double best_d[2] = {1e300, 1e300};
-    uint32_t best_j[2] = {0xFFFFFFFFu, 0xFFFFFFFFu}, best_id[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
-    for (int dz = -1; dz <= 1; ++dz)
-      for (int dy = -1; dy <= 1; ++dy)
-        for (int dx = -1; dx <= 1; ++dx) {
-          const uint64_t key = nos::pack_cell(cx + dx, cy + dy, cz + dz);
-          uint32_t h = nos::hash_cell(key) & map.table_mask;
-          uint32_t start = 0, count = 0;
-          for (uint32_t probe = 0; probe <= map.table_mask; ++probe) {
-            const uint64_t k = map.cell_key[h];
-            if (k == key) {
-              start = map.cell_start[h];
-              count = map.cell_count[h];
-              break;
-            }
-            if (k == nos::kEmptyCell) break;
-            h = (h + 1) & map.table_mask;
-          }
-          for (uint32_t j = start; j < start + count; ++j) {
-            const double ex = qx - map.mean[3 * size_t(j)], ey = qy - map.mean[3 * size_t(j) + 1],
-                         ez = qz - map.mean[3 * size_t(j) + 2];
-            const double d = ex * ex + ey * ey + ez * ez;
-            if (!(d < map.radius_sq)) continue;
-            const uint32_t id = map.orig_id[j];
-            if (d < best_d[0] || (d == best_d[0] && id < best_id[0])) {
-              best_d[1] = best_d[0];
-              best_j[1] = best_j[0];
-              best_id[1] = best_id[0];
-              best_d[0] = d;
-              best_j[0] = j;
-              best_id[0] = id;
-            } else if (d < best_d[1] || (d == best_d[1] && id < best_id[1])) {
-              best_d[1] = d;
-              best_j[1] = j;
-              best_id[1] = id;
-            }
-          }
-        }
+    nos::TwoNearest best;
+    nos::find_two_nearest(map, qx, qy, qz, best);
+    const uint32_t (&best_j)[2] = best.j;
     const bool ok0 = best_j[0] != 0xFFFFFFFFu, ok1 = best_j[1] != 0xFFFFFFFFu && max_neighbors > 1;
     idx0[i] = ok0 ? int32_t(best_j[0]) : -1;
     idx1[i] = ok1 ? int32_t(best_j[1]) : -1;

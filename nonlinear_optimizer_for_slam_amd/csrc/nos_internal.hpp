@@ -132,6 +132,8 @@ struct nos_ndt_map {
   uint32_t* d_cell_start = nullptr;
   uint32_t* d_cell_count = nullptr;
   unsigned long long* d_n_matches = nullptr;
+  uint32_t* d_dense_begin = nullptr;  // dense grid offsets (null when the bounding box is too large)
+  double* d_record = nullptr;         // [V][4] candidate records of the dense path
   nos::MapView view{};
 };
 
@@ -139,6 +141,7 @@ struct nos_scan {
   nos_ctx* ctx = nullptr;
   size_t n = 0;
   double* d_planes = nullptr;  // [3][n]
+  uint32_t* d_order = nullptr; // after nos_scan_sort_by_cell: original index of the point stored at each position
 };
 
 namespace nosd {

@@ -17,6 +17,82 @@ struct nos_map_stats {
 
 extern "C" {
 
+// Reorders the points of a scan by grid cell (lexicographic in the scan's own frame).  A rigid pose keeps
+// neighbours neighbours, so afterwards the 64 points of a wave of the matcher walk the same few cells of the map:
+// their candidate loads fall into the same cache lines and their loops have similar trip counts.  One radix sort
+// per scan (not per outer iteration).  The order of the matcher's output slots follows the new point order;
+// nos_scan_order returns the permutation.
+int nos_scan_sort_by_cell(nos_scan* scan, double cell_edge) {
+  if (!scan) return fail(NOS_ERR_INVALID_ARGUMENT, "scan is NULL");
+  if (!(cell_edge > 0.0) || !std::isfinite(cell_edge)) return fail(NOS_ERR_INVALID_ARGUMENT, "bad cell edge");
+  const size_t n = scan->n;
+  if (n == 0) return NOS_OK;
+  if (n >= 0xFFFFFFFFull) return fail(NOS_ERR_UNSUPPORTED, "too many points");
+  DeviceSlot& slot = scan->ctx->slots[0];
+  hipStream_t st = slot.stream;
+  DeviceBuffers buf;
+  uint64_t *keys = nullptr, *keys_sorted = nullptr;
+  uint32_t *idx = nullptr, *order = nullptr;
+  double* sorted = nullptr;
+  hipError_t e = hipSetDevice(slot.device);
+  if (e == hipSuccess) e = buf.alloc(&keys, n);
+  if (e == hipSuccess) e = buf.alloc(&keys_sorted, n);
+  if (e == hipSuccess) e = buf.alloc(&idx, n);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&order), n * sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sorted), n * 3 * sizeof(double));
+  if (e == hipSuccess) {
+    const dim3 grid(unsigned((n + 255) / 256));
+    hipLaunchKernelGGL(nos::voxel_key_kernel, grid, dim3(256), 0, st, scan->d_planes, scan->d_planes + n,
+                       scan->d_planes + 2 * n, uint64_t(n), 1.0 / cell_edge, keys, idx);
+    e = hipGetLastError();
+    size_t tmp_bytes = 0;
+    void* tmp = nullptr;
+    if (e == hipSuccess) e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys_sorted, idx, order, n, 0, 64, st);
+    if (e == hipSuccess) e = hipMalloc(&tmp, std::max(tmp_bytes, size_t(16)));
+    if (e == hipSuccess) buf.ptrs.push_back(tmp);
+    if (e == hipSuccess) e = rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys_sorted, idx, order, n, 0, 64, st);
+    for (int f = 0; f < 3 && e == hipSuccess; ++f) {
+      hipLaunchKernelGGL((nos::gather_plane_kernel<double, double>), grid, dim3(256), 0, st, scan->d_planes + size_t(f) * n,
+                         order, uint64_t(n), uint64_t(n), 0.0, sorted + size_t(f) * n);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess && scan->d_order != nullptr) {
+      // already sorted once: compose the permutations so that d_order still refers to the ORIGINAL indices
+      uint32_t* composed = nullptr;
+      e = buf.alloc(&composed, n);
+      if (e == hipSuccess) {
+        hipLaunchKernelGGL((nos::gather_plane_kernel<uint32_t, uint32_t>), grid, dim3(256), 0, st, scan->d_order, order,
+                           uint64_t(n), uint64_t(n), 0u, composed);
+        e = hipGetLastError();
+      }
+      if (e == hipSuccess) e = hipMemcpyAsync(order, composed, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, st);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+  }
+  if (e != hipSuccess) {
+    if (order) (void)hipFree(order);
+    if (sorted) (void)hipFree(sorted);
+    return fail(e == hipErrorOutOfMemory ? NOS_ERR_OUT_OF_MEMORY : NOS_ERR_HIP, "scan sort failed: %s", hipGetErrorString(e));
+  }
+  (void)hipFree(scan->d_planes);
+  if (scan->d_order) (void)hipFree(scan->d_order);
+  scan->d_planes = sorted;
+  scan->d_order = order;
+  return NOS_OK;
+}
+
+int nos_scan_order(const nos_scan* scan, uint32_t* order_out) {
+  if (!scan || (!order_out && scan->n > 0)) return fail(NOS_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (scan->d_order == nullptr) {
+    for (size_t i = 0; i < scan->n; ++i) order_out[i] = uint32_t(i);
+    return NOS_OK;
+  }
+  NOS_HIP_CHECK(hipSetDevice(scan->ctx->slots[0].device));
+  NOS_HIP_CHECK(hipMemcpy(order_out, scan->d_order, scan->n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  return NOS_OK;
+}
+
+
 int nos_map_stats_destroy(nos_map_stats* stats) {
   delete stats;
   return NOS_OK;

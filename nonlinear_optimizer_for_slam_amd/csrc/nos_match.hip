@@ -46,6 +46,51 @@ int nos_ndt_map_create(nos_ctx* ctx, size_t n_voxels, const double* means_xyz, c
       for (int k = 0; k < 9; ++k) s_sorted.push_back(sqrt_infos[9 * size_t(v) + k]);
     }
   }
+  // dense form of the grid (see MapView): bounding box of the occupied cells plus a one-cell border
+  std::vector<uint32_t> dense_begin;
+  std::vector<double> records;
+  int64_t lo[3] = {0, 0, 0}, dim[3] = {0, 0, 0};
+  if (!cells.empty() && env_int("NOS_MATCH_DENSE", 1) != 0) {
+    const int64_t bias = int64_t(1) << 20;
+    int64_t mn[3] = {INT64_MAX, INT64_MAX, INT64_MAX}, mx[3] = {INT64_MIN, INT64_MIN, INT64_MIN};
+    auto unpack = [&](uint64_t key, int64_t c[3]) {
+      c[0] = int64_t((key >> 42) & 0x1FFFFFull) - bias;
+      c[1] = int64_t((key >> 21) & 0x1FFFFFull) - bias;
+      c[2] = int64_t(key & 0x1FFFFFull) - bias;
+    };
+    for (const auto& kv : cells) {
+      int64_t c[3];
+      unpack(kv.first, c);
+      for (int k = 0; k < 3; ++k) {
+        mn[k] = std::min(mn[k], c[k]);
+        mx[k] = std::max(mx[k], c[k]);
+      }
+    }
+    double total = 1.0;
+    for (int k = 0; k < 3; ++k) {
+      lo[k] = mn[k] - 1;
+      dim[k] = mx[k] - mn[k] + 3;
+      total *= double(dim[k]);
+    }
+    if (total <= double(size_t(1) << 26)) {  // ≤ 64 M cells = 256 MB of offsets; beyond that the hash table serves
+      const size_t n_cells = size_t(dim[0]) * size_t(dim[1]) * size_t(dim[2]);
+      dense_begin.assign(n_cells + 1, 0);
+      // std::map iterates the packed keys in (x, y, z) lexicographic order = dense index order = record order
+      for (const auto& kv : cells) {
+        int64_t c[3];
+        unpack(kv.first, c);
+        const size_t idx = (size_t(c[0] - lo[0]) * size_t(dim[1]) + size_t(c[1] - lo[1])) * size_t(dim[2]) + size_t(c[2] - lo[2]);
+        dense_begin[idx + 1] = uint32_t(kv.second.size());
+      }
+      for (size_t c = 0; c < n_cells; ++c) dense_begin[c + 1] += dense_begin[c];
+      records.resize(orig.size() * 4);
+      for (size_t j = 0; j < orig.size(); ++j) {
+        for (int k = 0; k < 3; ++k) records[4 * j + k] = mean_sorted[3 * j + k];
+        const uint64_t bits = orig[j];
+        memcpy(&records[4 * j + 3], &bits, sizeof(double));
+      }
+    }
+  }
   nos_ndt_map* map = new (std::nothrow) nos_ndt_map();
   if (!map) return fail(NOS_ERR_OUT_OF_MEMORY, "host allocation failed");
   map->ctx = ctx;
@@ -58,6 +103,10 @@ int nos_ndt_map_create(nos_ctx* ctx, size_t n_voxels, const double* means_xyz, c
   if (e == hipSuccess) e = upload(&map->d_cell_start, starts);
   if (e == hipSuccess) e = upload(&map->d_cell_count, counts);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&map->d_n_matches), sizeof(unsigned long long));
+  if (e == hipSuccess && !dense_begin.empty()) {
+    e = upload(&map->d_dense_begin, dense_begin);
+    if (e == hipSuccess) e = upload(&map->d_record, records);
+  }
   if (e != hipSuccess) {
     nos_ndt_map_destroy(map);
     return fail(e == hipErrorOutOfMemory ? NOS_ERR_OUT_OF_MEMORY : NOS_ERR_HIP, "map upload failed: %s", hipGetErrorString(e));
@@ -71,6 +120,14 @@ int nos_ndt_map_create(nos_ctx* ctx, size_t n_voxels, const double* means_xyz, c
   map->view.table_mask = uint32_t(table_size - 1);
   map->view.inv_cell = inv_cell;
   map->view.radius_sq = search_radius_sq;
+  map->view.dense_begin = map->d_dense_begin;
+  map->view.record = map->d_record;
+  map->view.ox = lo[0];
+  map->view.oy = lo[1];
+  map->view.oz = lo[2];
+  map->view.nx = int32_t(dim[0]);
+  map->view.ny = int32_t(dim[1]);
+  map->view.nz = int32_t(dim[2]);
   *out_map = map;
   return NOS_OK;
 }
@@ -85,6 +142,8 @@ int nos_ndt_map_destroy(nos_ndt_map* map) {
   if (map->d_cell_start) (void)hipFree(map->d_cell_start);
   if (map->d_cell_count) (void)hipFree(map->d_cell_count);
   if (map->d_n_matches) (void)hipFree(map->d_n_matches);
+  if (map->d_dense_begin) (void)hipFree(map->d_dense_begin);
+  if (map->d_record) (void)hipFree(map->d_record);
   delete map;
   return NOS_OK;
 }
@@ -139,6 +198,7 @@ int nos_scan_destroy(nos_scan* scan) {
   if (!scan) return NOS_OK;
   (void)hipSetDevice(scan->ctx->slots[0].device);
   if (scan->d_planes) (void)hipFree(scan->d_planes);
+  if (scan->d_order) (void)hipFree(scan->d_order);
   delete scan;
   return NOS_OK;
 }

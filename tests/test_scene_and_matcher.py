@@ -247,3 +247,34 @@ def test_gpu_map_build_edge_cases(ctx):
     gm0, st0 = api.NdtMap.build(ctx, np.zeros((0, 3)), 1.0, 1.0)
     assert len(gm0) == 0 and len(st0["counts"]) == 0
     gm0.close()
+
+
+@pytest.mark.gpu
+def test_cell_sorted_scan_gives_the_same_matches_in_permuted_order(ctx):
+    """nos_scan_sort_by_cell only changes the order of the points (and therefore of the output slots): slot pair j of
+    the sorted scan equals slot pair order[j] of the unsorted one, bit for bit; sorting twice composes the orders."""
+    from nonlinear_optimizer_for_slam_amd import api
+    rng = np.random.default_rng(11)
+    V, n = 4000, 30_000
+    means = rng.uniform([-20, -20, -3], [20, 20, 3], size=(V, 3))
+    S = rng.normal(size=(V, 3, 3))
+    pts = means[rng.integers(0, V, n)] + 0.3 * rng.normal(size=(n, 3))
+    R = helpers.rot_xyz(0.02, -0.01, 0.4)
+    t = np.array([0.3, -0.2, 0.1])
+    m = api.NdtMap(ctx, means, S, None, 1.0)
+    plain = api.Scan(ctx, pts)
+    ds0, n0 = m.match(plain, R, t, 2, "f64")
+    ref = api.download(ds0).reshape(15, n, 2)
+    for passes in (1, 2):
+        sc = api.Scan(ctx, pts, sort_cell=1.0)
+        if passes == 2:
+            sc.sort_by_cell(0.37)
+        order = sc.order
+        assert np.array_equal(np.sort(order), np.arange(n, dtype=np.uint32))
+        ds1, n1 = m.match(sc, R, t, 2, "f64")
+        got = api.download(ds1).reshape(15, n, 2)
+        assert n1 == n0 and np.array_equal(got, ref[:, order, :])
+        ds1.close()
+        sc.close()
+    np.testing.assert_array_equal(plain.order, np.arange(n, dtype=np.uint32))
+    ds0.close()

@@ -22,6 +22,16 @@ for dtype in ("f64", "f32"):
         t0 = time.perf_counter(); ds, nm = m.match(sc, Rt, tt, 2, dtype); dt = time.perf_counter() - t0
         print("match %s: %.2f ms, %d matches of %d slots, %.1f M points/s" % (dtype, 1e3*dt, nm, len(ds), n/dt/1e6))
         ds.close()
+t0 = time.perf_counter(); sc2 = api.Scan(ctx, pts, sort_cell=1.0); t1 = time.perf_counter()
+print("scan upload + sort by cell: %.1f ms" % (1e3 * (t1 - t0)))
+for rep in range(3):
+    t0 = time.perf_counter(); ds, nm = m.match(sc2, Rt, tt, 2, "f64"); dt = time.perf_counter() - t0
+    print("match f64 (cell-sorted scan): %.2f ms, %d matches, %.1f M points/s" % (1e3*dt, nm, n/dt/1e6))
+    ds.close()
+for rep in range(3):
+    t0 = time.perf_counter(); ds, nm = m.match_indexed(sc2, Rt, tt, 2, "f64", sort_by_voxel=False); dt = time.perf_counter() - t0
+    print("match_indexed f64 (cell-sorted scan, no voxel sort): %.2f ms, %d matches" % (1e3*dt, nm))
+    ds.close()
 # ingestion paths
 for dtype in ("f64",):
     t0 = time.perf_counter(); ds = NdtDataset.from_planes(ctx, planes, dtype); dt = time.perf_counter() - t0
