@@ -49,6 +49,9 @@ def parse_args():
     ap.add_argument("--loop", default="device", choices=["device", "host"],
                     help="device: LM loop resident on the GPU (nos_ndt6_solve, the product default); "
                          "host: the loop on the host around nos_ndt6_accumulate")
+    ap.add_argument("--prewarm-ms", type=float, default=400.0,
+                    help="untimed GPU activity (the same iteration) before the W warm-up steps: the part needs ≈ 0.1-0.3 s "
+                         "of load to reach its steady clocks (tools/clock_ramp_probe.py); reported as prewarm_ms")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="time budget per CPU baseline leg")
     return ap.parse_args()
@@ -125,19 +128,28 @@ def main():
     torch = None
     dist = None
     force_dist = os.environ.get("NOS_BENCH_FORCE_DIST", "0") == "1"  # exercise the N>1 code path on one GPU
+    # NOS_BENCH_SHARED_GPU=1: rehearsal of the N > 1 path on a one-GPU box — every rank uses device 0 and the launcher
+    # side runs over gloo (RCCL refuses two ranks on one device); the data path (mailbox exchange) is the real one.
+    shared_gpu = os.environ.get("NOS_BENCH_SHARED_GPU", "0") == "1"
+    tdev = "cpu" if shared_gpu else "cuda"
+    if shared_gpu:
+        local_rank = 0
     if world > 1 or force_dist:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
         if force_dist and world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
         with _StdoutToStderr():
-            dist.init_process_group("nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
-            probe = torch.ones(1, device="cuda")
-            dist.all_reduce(probe)  # creates torch's communicator (and its banner) now
-            torch.cuda.synchronize()
+            if shared_gpu:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                torch.cuda.set_device(local_rank)
+                dist.init_process_group("nccl", rank=rank, world_size=world,
+                                        device_id=torch.device("cuda", local_rank))
+                probe = torch.ones(1, device="cuda")
+                dist.all_reduce(probe)  # creates torch's communicator (and its banner) now
+                torch.cuda.synchronize()
 
     n_local = args.points
     blocks_per_rank = (n_local + 65535) // 65536
@@ -152,31 +164,40 @@ def main():
     else:
         ds = NdtDataset.from_planes(ctx, planes, args.dtype)
 
-    # Data-path collective for N > 1: a native RCCL all-reduce of the 28 doubles inside
-    # libnos_hip.so (the LM loop then runs entirely in C++, as at N = 1).  It is bootstrapped
-    # and self-tested through torch.distributed; if any rank cannot bring it up, every rank
-    # uses torch.distributed.all_reduce from a Python callback instead (NOS_BENCH_COMM=torch
-    # forces that).
+    # Data-path exchange for N > 1 (the 28 doubles of every iteration), best first; each candidate is brought up and
+    # self-tested on every rank and adopted only if ALL ranks succeed (collective MIN vote), else the next one is tried:
+    #   "mailbox"     sums exchanged INSIDE the assemble launch through a shared-memory mailbox (nos_ctx_comm_init_shm):
+    #                 no extra kernel, no RCCL call, no host step per iteration; the LM loop is device resident
+    #   "rccl-native" ncclAllReduce issued by libnos_hip.so on the launch stream + a one-wave step kernel
+    #   "torch.distributed"  all_reduce from a Python callback around nos_ndt6_accumulate_async (host loop)
+    # NOS_BENCH_COMM = mailbox | rccl | torch pins the starting point of that chain.
     comm_mode = "none"
     if dist is not None:
         comm_mode = "torch.distributed"
-        if os.environ.get("NOS_BENCH_COMM", "rccl") == "rccl":
+        want = os.environ.get("NOS_BENCH_COMM", "mailbox")
+        chain = {"mailbox": ["mailbox", "rccl-native"], "rccl": ["rccl-native"], "torch": []}.get(want, [])
+        for candidate in chain:
             ok = 1.0
             try:
                 with _StdoutToStderr():
-                    ctx.comm_init_from_torch()
-                    got = ctx.comm_allreduce([rank + 1.0, 1.0])
-                if abs(got[0] - world * (world + 1) / 2.0) > 1e-12 or abs(got[1] - world) > 1e-12:
-                    raise RuntimeError("native RCCL self-test mismatch: %r" % (got,))
+                    if candidate == "mailbox":
+                        ctx.comm_init_shm_from_torch()
+                    else:
+                        ctx.comm_init_from_torch()
+                    for _ in range(3):
+                        got = ctx.comm_allreduce([rank + 1.0, 1.0])
+                        if abs(got[0] - world * (world + 1) / 2.0) > 1e-12 or abs(got[1] - world) > 1e-12:
+                            raise RuntimeError("%s self-test mismatch: %r" % (candidate, got))
             except Exception as exc:  # noqa: BLE001
-                print("[bench] native RCCL unavailable on rank %d: %s" % (rank, exc), file=sys.stderr)
+                print("[bench] %s unavailable on rank %d: %s" % (candidate, rank, exc), file=sys.stderr)
                 ok = 0.0
-            flag = torch.tensor([ok], device="cuda")
+            flag = torch.tensor([ok], device=tdev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if float(flag.item()) > 0.5:
-                comm_mode = "rccl-native"
-            elif ctx.comm_size > 0:
-                raise RuntimeError("native RCCL came up on this rank but not on all ranks")
+                comm_mode = candidate
+                break
+            if ctx.comm_size > 0:
+                ctx.comm_destroy()  # came up here but not everywhere: drop it and try the next candidate
     if not (rank == 0 and world == 1 and not args.no_cpu_baseline):
         del planes
         planes = None
@@ -226,9 +247,19 @@ def main():
     def fence():
         ctx.synchronize()
         if dist is not None:
-            torch.cuda.synchronize()
+            if not shared_gpu:
+                torch.cuda.synchronize()
             dist.barrier()
 
+    t_pre = time.perf_counter()
+    # a fixed number of iterations (≈ 0.2 ms each at the default size), identical on every rank: the exchange inside
+    # the iterations is collective, a time-based loop would let ranks disagree on the count
+    for _ in range(int(args.prewarm_ms / 0.2) // 50):
+        iterate(50)
+    fence()
+    prewarm_ms = 1e3 * (time.perf_counter() - t_pre)
+    pose_t[:] = 0.0                       # the warm-up and the timed steps start from the initial pose again
+    pose_R[:] = np.eye(3).reshape(-1)
     if args.warmup > 0:
         iterate(args.warmup)
     fence()
@@ -236,7 +267,7 @@ def main():
     # loop at N = 1: the launches form one back-to-back train, so ONE event pair brackets the whole train (an event
     # between two queued kernels would serialise their dispatch) and the duration per launch is train / launches — an
     # upper bound of the kernel's own duration.  Host loop / N > 1: an event pair around every 4th assemble launch.
-    bracket = comm_mode == "none" and args.loop == "device"
+    bracket = comm_mode in ("none", "mailbox") and args.loop == "device"
     if os.environ.get("NOS_BENCH_NO_EVENTS", "0") != "1":
         ctx.profile_begin(args.steps + 8, sample_every=0 if bracket else 4)
     t0 = time.perf_counter()
@@ -245,7 +276,7 @@ def main():
     elapsed = time.perf_counter() - t0
     n_timed, k_mean_ms, k_min_ms, k_max_ms = ctx.profile_end()
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -264,6 +295,7 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
+        "prewarm_ms": prewarm_ms,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -281,7 +313,8 @@ def main():
             "loop": args.loop if comm_mode != "torch.distributed" else "host",
             "step": ("LM iteration, device resident: assemble kernel + in-launch final reduce%s + 6x6 LDLT / pose update "
                      "/ lambda schedule on the GPU, next launch already queued"
-                     % (" + RCCL all-reduce(28 f64) + step kernel" if world > 1 else ""))
+                     % ("" if world == 1 else (" + in-launch mailbox all-reduce(28 f64)" if comm_mode == "mailbox"
+                                               else " + RCCL all-reduce(28 f64) + step kernel")))
                     if (args.loop == "device" and comm_mode != "torch.distributed") else
                     ("LM iteration: assemble kernel + final reduce%s + 224 B readback + host 6x6 LDLT/pose update"
                      % (" + RCCL all-reduce(28 f64)" if world > 1 else "")),

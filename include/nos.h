@@ -110,6 +110,18 @@ int nos_ctx_synchronize(nos_ctx* ctx);
 int nos_comm_get_unique_id(unsigned char id[NOS_COMM_ID_BYTES]);
 int nos_ctx_comm_init(nos_ctx* ctx, int n_ranks, int rank, const unsigned char id[NOS_COMM_ID_BYTES]);
 int nos_ctx_comm_size(const nos_ctx* ctx); /* 0 if no communicator */
+/* Alternative communicator for ranks on ONE node: a mailbox in POSIX shared memory (name, starting with '/',
+ * chosen by the caller and identical on every rank; every rank creates-or-opens it, rank 0 may call
+ * nos_comm_shm_unlink once all ranks have attached).  The sums are then exchanged INSIDE the launch: the workgroup
+ * that completes a GPU's sums stores them in its mailbox slot, waits (bounded) for the other ranks' slots and adds
+ * them in rank order, so nos_*_accumulate and nos_*_solve return identical bits on every rank with no extra
+ * kernel, no RCCL call and no host step per iteration.  This is the reference's "sum the per-thread partials"
+ * (MDM/..._analytic_simd.cc:70-75) across processes.  At most 64 ranks; all ranks must issue the same sequence of
+ * calls; a rank that never arrives makes the others return NOS_ERR_HIP after 3 s instead of hanging. */
+int nos_ctx_comm_init_shm(nos_ctx* ctx, int n_ranks, int rank, const char* shm_name);
+int nos_comm_shm_unlink(const char* shm_name);
+/* Leaves whichever communicator the context has (collective for RCCL); nos_ctx_destroy does it implicitly. */
+int nos_ctx_comm_destroy(nos_ctx* ctx);
 /* Sum `count` (<= 28) host doubles over the ranks, in place (diagnostic / self-test). */
 int nos_ctx_comm_allreduce(nos_ctx* ctx, double* values, int count);
 

@@ -52,6 +52,10 @@ def new_unique_id():
     return buf.raw
 
 
+def shm_unlink(name):
+    check(hip_lib().nos_comm_shm_unlink(name.encode()), "nos_comm_shm_unlink")
+
+
 class Context:
     """nos_ctx: one HIP stream + workspace per listed device (include/nos.h)."""
 
@@ -94,6 +98,29 @@ class Context:
         payload = [new_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(payload, src=0, group=group)
         self.comm_init(world, rank, payload[0])
+
+    def comm_init_shm(self, n_ranks, rank, name):
+        """Collective (ranks of one node): join the shared-memory mailbox communicator `name` ('/...'); the sums are
+        then exchanged inside the launch (nos_ctx_comm_init_shm)."""
+        check(self._lib.nos_ctx_comm_init_shm(self._h, n_ranks, rank, name.encode()), "nos_ctx_comm_init_shm")
+
+    def comm_init_shm_from_torch(self, group=None):
+        """Bootstrap the mailbox communicator through an initialised torch.distributed group: rank 0 picks a fresh
+        name, every rank attaches, rank 0 unlinks the name once all are in (the mapping stays alive)."""
+        import torch.distributed as dist
+        import uuid
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        payload = ["/nos_%s" % uuid.uuid4().hex if rank == 0 else None]
+        dist.broadcast_object_list(payload, src=0, group=group)
+        try:
+            self.comm_init_shm(world, rank, payload[0])
+        finally:
+            dist.barrier(group=group)
+            if rank == 0:
+                shm_unlink(payload[0])
+
+    def comm_destroy(self):
+        check(self._lib.nos_ctx_comm_destroy(self._h), "nos_ctx_comm_destroy")
 
     @property
     def comm_size(self):

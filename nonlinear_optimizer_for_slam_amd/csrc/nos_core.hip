@@ -339,6 +339,28 @@ __global__ void publish_kernel(const double* __restrict__ src, int n, double* ds
   }
 }
 
+// Mailbox descriptor for the in-launch cross-rank exchange (base == null when the context has no shm communicator).
+nos::Mailbox mailbox_of(const nos_ctx* ctx, const DeviceSlot& slot) {
+  nos::Mailbox mb{};
+  if (ctx->shm_dev == nullptr) return mb;
+  mb.base = ctx->shm_dev;
+  mb.round = ctx->d_round;
+  mb.error_host = reinterpret_cast<unsigned int*>(slot.h_out_dev + kCommErrorSlot);
+  mb.n_ranks = ctx->comm_ranks;
+  mb.rank = ctx->comm_rank;
+  return mb;
+}
+
+int check_mailbox_error(const nos_ctx* ctx, DeviceSlot& slot) {
+  if (ctx->shm_dev == nullptr) return NOS_OK;
+  volatile unsigned int* err = reinterpret_cast<volatile unsigned int*>(slot.h_out + kCommErrorSlot);
+  if (*err != 0u) {
+    *err = 0u;
+    return fail(NOS_ERR_HIP, "mailbox all-reduce timed out: a peer rank did not arrive (ranks must run the same sequence of calls)");
+  }
+  return NOS_OK;
+}
+
 // Spin on the host-mapped sequence word the last block stores after the result; falls back
 // to a stream synchronise if the word has not arrived after a generous bound, so a protocol
 // error can never hang the caller.
@@ -364,7 +386,7 @@ int wait_for_sequence(DeviceSlot& slot) { return wait_for_sequence(slot, slot.se
 // (the reference sums its per-thread partials the same way).
 int accumulate_sync(nos_dataset* ds, const Request& rq, double* out) {
   nos_ctx* ctx = ds->ctx;
-  const bool fused = env_int("NOS_FUSED", 1) != 0;
+  const bool fused = env_int("NOS_FUSED", 1) != 0 || ctx->shm_dev != nullptr;  // the mailbox exchange lives in the fused tail
   if (ctx->comm != nullptr) {
     // one process per GPU: local sums → RCCL all-reduce of the n_out doubles (in place, on the
     // same stream) → publish to pinned host memory.  Every rank receives identical bits.
@@ -394,6 +416,7 @@ int accumulate_sync(nos_dataset* ds, const Request& rq, double* out) {
       // sequence word straight into pinned host memory (no second kernel, no memcpy)
       nos::FusedFinal fin{slot.counter, nullptr, slot.h_out_dev,
                           reinterpret_cast<unsigned long long*>(slot.h_out_dev + kSeqSlot), ++slot.seq};
+      fin.mail = mailbox_of(ctx, slot);
       int rc = launch_assemble(ds, sh, rq, slot.partials, fin, slot.stream, &rows);
       if (rc != NOS_OK) return rc;
     } else {
@@ -409,6 +432,7 @@ int accumulate_sync(nos_dataset* ds, const Request& rq, double* out) {
     DeviceSlot& slot = ctx->slots[sh.slot];
     if (fused) {
       int rc = wait_for_sequence(slot);
+      if (rc == NOS_OK) rc = check_mailbox_error(ctx, slot);
       if (rc != NOS_OK) return rc;
     } else {
       NOS_HIP_CHECK(hipSetDevice(slot.device));
@@ -434,8 +458,9 @@ int accumulate_async(nos_dataset* ds, const Request& rq, double* d_out) {
     NOS_RCCL_CHECK(Rccl()->AllReduce(d_out, d_out, size_t(rq.n_out), ncclDouble, ncclSum, ctx->comm, slot.stream));
     return NOS_OK;
   }
-  if (env_int("NOS_FUSED", 1) != 0) {
+  if (env_int("NOS_FUSED", 1) != 0 || ctx->shm_dev != nullptr) {
     nos::FusedFinal fin{slot.counter, d_out, nullptr, nullptr, 0};
+    fin.mail = mailbox_of(ctx, slot);
     return launch_assemble(ds, sh, rq, slot.partials, fin, slot.stream, &rows);
   }
   int rc = launch_assemble(ds, sh, rq, slot.partials, nos::FusedFinal{}, slot.stream, &rows);
@@ -528,6 +553,7 @@ int lm_solve(nos_dataset* ds, const Request& rq, const nos_lm_options* opt, doub
     fin.counter = slot.counter;
     fin.lm = slot.d_lm;
     fin.seq = ++slot.seq;
+    fin.mail = mailbox_of(ctx, slot);
     if (step_in_launch) {
       fin.out_host = entry;
       fin.seq_host = seq_dev;
@@ -556,6 +582,7 @@ int lm_solve(nos_dataset* ds, const Request& rq, const nos_lm_options* opt, doub
   while (rc == NOS_OK && launched < std::min(window, opt->max_iterations)) rc = launch_one();
   while (rc == NOS_OK && completed < launched) {
     rc = wait_for_sequence(slot, base_seq + completed + 1);
+    if (rc == NOS_OK) rc = check_mailbox_error(ctx, slot);
     if (rc != NOS_OK) break;
     if (!st.done) {
       const double* e = slot.h_log + size_t(completed % kLogSlots) * nos::kLogEntryDoubles;
@@ -572,6 +599,11 @@ int lm_solve(nos_dataset* ds, const Request& rq, const nos_lm_options* opt, doub
       // wall_clock64 ticks (10 ns): start of the finishing workgroup, its ticket, step begin, step done, log written
       fprintf(stderr, "[lm-timing] it %d: loop+ticket %.2f us, rows->sums %.2f us, step %.2f us, log %.2f us\n", completed,
               (e[51] - e[50]) * 0.01, (e[52] - e[51]) * 0.01, (e[53] - e[52]) * 0.01, (e[54] - e[53]) * 0.01);
+      if (ctx->shm_host != nullptr) {
+        const double* mbx = static_cast<const double*>(ctx->shm_host) + size_t(ctx->comm_rank) * 2 * nos::kMailSlotDoubles;
+        fprintf(stderr, "[lm-timing]        mailbox: store+flag %.2f us, poll %.2f us, gather %.2f us\n", mbx[40] * 0.01,
+                mbx[41] * 0.01, mbx[42] * 0.01);
+      }
       fprintf(stderr, "[lm-timing]        a block: prologue %.2f us, loads+math %.2f us, block reduce+store %.2f us\n",
               e[56] * 0.01, e[57] * 0.01, e[58] * 0.01);
 #endif
@@ -905,7 +937,7 @@ int nos_ctx_create(const int* device_ids, int n_devices, nos_ctx** out_ctx) {
   return NOS_OK;
 }
 
-int nos_ctx_destroy(nos_ctx* ctx) {
+int nos_ctx_comm_destroy(nos_ctx* ctx) {
   if (!ctx) return NOS_OK;
   if (ctx->comm != nullptr) {
     if (!ctx->slots.empty()) {
@@ -915,6 +947,26 @@ int nos_ctx_destroy(nos_ctx* ctx) {
     (void)Rccl()->CommDestroy(ctx->comm);
     ctx->comm = nullptr;
   }
+  if (ctx->shm_host != nullptr) {
+    if (!ctx->slots.empty()) {
+      (void)hipSetDevice(ctx->slots[0].device);
+      (void)hipStreamSynchronize(ctx->slots[0].stream);
+    }
+    (void)hipHostUnregister(ctx->shm_host);
+    munmap(ctx->shm_host, ctx->shm_bytes);
+    if (ctx->d_round) (void)hipFree(ctx->d_round);
+    ctx->shm_host = nullptr;
+    ctx->shm_dev = nullptr;
+    ctx->d_round = nullptr;
+  }
+  ctx->comm_ranks = 1;
+  ctx->comm_rank = 0;
+  return NOS_OK;
+}
+
+int nos_ctx_destroy(nos_ctx* ctx) {
+  if (!ctx) return NOS_OK;
+  (void)nos_ctx_comm_destroy(ctx);
   for (DeviceSlot& s : ctx->slots) {
     (void)hipSetDevice(s.device);
     if (s.own_stream) {
@@ -1142,18 +1194,76 @@ int nos_ctx_comm_init(nos_ctx* ctx, int n_ranks, int rank, const unsigned char i
   return NOS_OK;
 }
 
-int nos_ctx_comm_size(const nos_ctx* ctx) { return (ctx && ctx->comm) ? ctx->comm_ranks : 0; }
+int nos_ctx_comm_size(const nos_ctx* ctx) { return (ctx && (ctx->comm || ctx->shm_dev)) ? ctx->comm_ranks : 0; }
+
+int nos_ctx_comm_init_shm(nos_ctx* ctx, int n_ranks, int rank, const char* shm_name) {
+  if (!ctx || !shm_name || shm_name[0] != '/' || n_ranks < 1 || n_ranks > 64 || rank < 0 || rank >= n_ranks)
+    return fail(NOS_ERR_INVALID_ARGUMENT, "bad comm arguments (name must start with '/', at most 64 ranks)");
+  if (ctx->slots.size() != 1) return fail(NOS_ERR_UNSUPPORTED, "a communicator needs a single-device context");
+  if (ctx->comm != nullptr || ctx->shm_dev != nullptr) return fail(NOS_ERR_INVALID_ARGUMENT, "communicator already initialised");
+  DeviceSlot& slot = ctx->slots[0];
+  NOS_HIP_CHECK(hipSetDevice(slot.device));
+  size_t bytes = size_t(n_ranks) * 2 * nos::kMailSlotDoubles * sizeof(double);
+  bytes = (bytes + 4095) & ~size_t(4095);
+  const int fd = shm_open(shm_name, O_CREAT | O_RDWR, 0600);
+  if (fd < 0) return fail(NOS_ERR_HIP, "shm_open(%s) failed: %s", shm_name, strerror(errno));
+  // every rank sizes the segment (idempotent); pages of a fresh segment read as zero = round 0 everywhere
+  if (ftruncate(fd, off_t(bytes)) != 0) {
+    const int e = errno;
+    close(fd);
+    return fail(NOS_ERR_HIP, "ftruncate(%s) failed: %s", shm_name, strerror(e));
+  }
+  void* host = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (host == MAP_FAILED) return fail(NOS_ERR_HIP, "mmap(%s) failed: %s", shm_name, strerror(errno));
+  hipError_t e = hipHostRegister(host, bytes, hipHostRegisterMapped | hipHostRegisterPortable);
+  void* dev = nullptr;
+  if (e == hipSuccess) {
+    e = hipHostGetDevicePointer(&dev, host, 0);
+    if (e != hipSuccess) (void)hipHostUnregister(host);
+  }
+  unsigned long long* d_round = nullptr;
+  if (e == hipSuccess) {
+    e = hipMalloc(reinterpret_cast<void**>(&d_round), sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(d_round, 0, sizeof(unsigned long long));
+    if (e != hipSuccess) (void)hipHostUnregister(host);
+  }
+  if (e != hipSuccess) {
+    if (d_round) (void)hipFree(d_round);
+    munmap(host, bytes);
+    return fail(NOS_ERR_HIP, "mapping the mailbox into the GPU failed: %s", hipGetErrorString(e));
+  }
+  *reinterpret_cast<volatile unsigned int*>(slot.h_out + kCommErrorSlot) = 0u;
+  ctx->shm_host = host;
+  ctx->shm_bytes = bytes;
+  ctx->shm_dev = static_cast<double*>(dev);
+  ctx->d_round = d_round;
+  ctx->comm_ranks = n_ranks;
+  ctx->comm_rank = rank;
+  return NOS_OK;
+}
+
+int nos_comm_shm_unlink(const char* shm_name) {
+  if (!shm_name) return fail(NOS_ERR_INVALID_ARGUMENT, "name is NULL");
+  if (shm_unlink(shm_name) != 0 && errno != ENOENT) return fail(NOS_ERR_HIP, "shm_unlink(%s) failed: %s", shm_name, strerror(errno));
+  return NOS_OK;
+}
 
 int nos_ctx_comm_allreduce(nos_ctx* ctx, double* values, int count) {
   if (!ctx || !values || count < 1 || count > kMaxOut) return fail(NOS_ERR_INVALID_ARGUMENT, "bad allreduce arguments");
-  if (ctx->comm == nullptr) return fail(NOS_ERR_INVALID_ARGUMENT, "no communicator");
+  if (ctx->comm == nullptr && ctx->shm_dev == nullptr) return fail(NOS_ERR_INVALID_ARGUMENT, "no communicator");
   DeviceSlot& slot = ctx->slots[0];
   NOS_HIP_CHECK(hipSetDevice(slot.device));
   NOS_HIP_CHECK(hipMemcpyAsync(slot.d_out, values, sizeof(double) * count, hipMemcpyHostToDevice, slot.stream));
-  NOS_RCCL_CHECK(Rccl()->AllReduce(slot.d_out, slot.d_out, size_t(count), ncclDouble, ncclSum, ctx->comm, slot.stream));
+  if (ctx->shm_dev != nullptr) {
+    hipLaunchKernelGGL(nos::mailbox_allreduce_kernel, dim3(1), dim3(64), 0, slot.stream, mailbox_of(ctx, slot), slot.d_out, count);
+    NOS_HIP_CHECK(hipGetLastError());
+  } else {
+    NOS_RCCL_CHECK(Rccl()->AllReduce(slot.d_out, slot.d_out, size_t(count), ncclDouble, ncclSum, ctx->comm, slot.stream));
+  }
   NOS_HIP_CHECK(hipMemcpyAsync(values, slot.d_out, sizeof(double) * count, hipMemcpyDeviceToHost, slot.stream));
   NOS_HIP_CHECK(hipStreamSynchronize(slot.stream));
-  return NOS_OK;
+  return check_mailbox_error(ctx, slot);
 }
 
 int nos_ctx_profile_begin(nos_ctx* ctx, int max_launches, int sample_every) {

@@ -3,6 +3,9 @@
 
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
 #include <rccl/rccl.h>
 
 #include <algorithm>
@@ -94,6 +97,12 @@ struct nos_ctx {
   int tile_log2 = -1;     // -1 = default; 0 = planar
   ncclComm_t comm = nullptr;  // set by nos_ctx_comm_init: accumulate results are summed over its ranks
   int comm_ranks = 1;
+  int comm_rank = 0;
+  // shared-memory mailbox communicator (nos_ctx_comm_init_shm): the sums are exchanged inside the launch
+  void* shm_host = nullptr;            // mmap of the POSIX shm segment
+  size_t shm_bytes = 0;
+  double* shm_dev = nullptr;           // its device address (hipHostRegister, mapped)
+  unsigned long long* d_round = nullptr;  // device word: exchange rounds completed
 };
 
 namespace nosd {
@@ -147,6 +156,7 @@ struct nos_scan {
 namespace nosd {
 
 constexpr int kSeqSlot = 32;  // index (in doubles) of the sequence word inside the pinned block
+constexpr int kCommErrorSlot = 40;  // index (in doubles) of the mailbox time-out flag (an unsigned int) in that block
 
 template <typename T>
 hipError_t upload(T** dptr, const std::vector<T>& host) {

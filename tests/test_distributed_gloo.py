@@ -100,3 +100,96 @@ def test_two_processes_sharing_one_gpu_match_the_single_process_solve(tmp_path):
     assert int(r0["it"]) == single.report.iterations
     dt, dq = helpers.pose_delta(r0["R"], r0["t"], pose.R, pose.t)
     assert dt < 1e-9 and dq < 1e-9
+
+
+# ------------------------------------------------------------------ in-launch mailbox all-reduce (nos_ctx_comm_init_shm)
+
+def _mailbox_worker(rank, world, name, n, out_dir):
+    """One process per rank, all on GPU 0 (a one-GPU box): shard of the correspondences, mailbox communicator,
+    one accumulate and one device-resident solve.  No torch, no RCCL: the exchange happens inside the launches."""
+    import numpy as np
+    from nonlinear_optimizer_for_slam_amd import Context, NdtDataset, distributed, synth
+    loss = ("exponential", 1.0, 1.0)
+    planes = synth.ndt_planes(n, 2000)
+    lo, hi = distributed.shard_range(n, rank, world)
+    ctx = Context((0,))
+    ctx.comm_init_shm(world, rank, name)
+    assert ctx.comm_size == world
+    ds = NdtDataset.from_planes(ctx, np.ascontiguousarray(planes[:, lo:hi]), "f64")
+    probe = ctx.comm_allreduce([rank + 1.0, 1.0])
+    R_test = np.array([[0.9987, -0.0499, -0.0199], [0.0501, 0.9987, 0.0095], [0.0194, -0.0105, 0.9998]])
+    out = ds.accumulate6(R_test, [-0.1, 0.05, 0.2], loss)
+    R, t, rep = ds.solve6(np.eye(3), np.zeros(3), loss, max_iterations=60)
+    # a second solve right behind the first: rounds keep alternating across solves and no-op launches
+    R2, t2, rep2 = ds.solve6(np.eye(3), np.zeros(3), loss, max_iterations=60, launches_in_flight=7)
+    np.savez(os.path.join(out_dir, "mail_rank%d.npz" % rank), probe=probe, out=out, R=R, t=t, it=rep["iterations"],
+             cost=rep["cost_history"], R2=R2, t2=t2, ok=int(rep["ok"] and rep2["ok"]))
+    ds.close()
+    ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_mailbox_allreduce_ranks_agree_bitwise_and_match_one_process(tmp_path, world):
+    """SURVEY §8e with the exchange inside the launch: W processes (sharing GPU 0 here), each owning a contiguous shard;
+    every rank must end with identical bits, equal to the single-process result up to summation order."""
+    import uuid
+    from nonlinear_optimizer_for_slam_amd import Context, NdtDataset, api, synth
+    from tests import helpers
+    n = 90_001
+    name = "/nos_test_%s" % uuid.uuid4().hex
+    try:
+        mp.spawn(_mailbox_worker, args=(world, name, n, str(tmp_path)), nprocs=world, join=True)
+    finally:
+        api.shm_unlink(name)
+    ranks = [np.load(tmp_path / ("mail_rank%d.npz" % r)) for r in range(world)]
+    for r in ranks:
+        assert int(r["ok"]) == 1
+        np.testing.assert_array_equal(r["probe"], [world * (world + 1) / 2.0, float(world)])
+        for key in ("out", "R", "t", "cost", "R2", "t2"):
+            assert np.array_equal(r[key], ranks[0][key]), key          # identical bits on every rank
+        assert int(r["it"]) == int(ranks[0]["it"])
+    assert np.array_equal(ranks[0]["R"], ranks[0]["R2"]) and np.array_equal(ranks[0]["t"], ranks[0]["t2"])
+    loss = ("exponential", 1.0, 1.0)
+    ctx = Context((0,))
+    ds = NdtDataset.from_planes(ctx, synth.ndt_planes(n, 2000), "f64")
+    R_test = np.array([[0.9987, -0.0499, -0.0199], [0.0501, 0.9987, 0.0095], [0.0194, -0.0105, 0.9998]])
+    helpers.assert_normal_equations_close(ranks[0]["out"], ds.accumulate6(R_test, [-0.1, 0.05, 0.2], loss), 6, 1e-12)
+    R, t, rep = ds.solve6(np.eye(3), np.zeros(3), loss, max_iterations=60)
+    assert rep["iterations"] == int(ranks[0]["it"])
+    dt, dq = helpers.pose_delta(ranks[0]["R"].reshape(3, 3), ranks[0]["t"], R.reshape(3, 3), t)
+    assert dt < 1e-10 and dq < 1e-10, (dt, dq)
+    ds.close()
+    ctx.close()
+
+
+def _mailbox_lonely_worker(_rank, name, out_dir):
+    import numpy as np
+    from nonlinear_optimizer_for_slam_amd import Context, NdtDataset, _lib, synth
+    ctx = Context((0,))
+    ctx.comm_init_shm(2, 0, name)      # rank 1 never shows up
+    ds = NdtDataset.from_planes(ctx, synth.ndt_planes(5000, 100), "f64")
+    import time
+    t0 = time.time()
+    try:
+        ds.accumulate6(np.eye(3), np.zeros(3), None)
+        msg = "no error"
+    except _lib.NosError as exc:
+        msg = str(exc)
+    with open(os.path.join(out_dir, "lonely.txt"), "w") as f:
+        f.write("%.1f\n%s\n" % (time.time() - t0, msg))
+    ds.close()
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_mailbox_allreduce_reports_a_missing_peer_instead_of_hanging(tmp_path):
+    import uuid
+    from nonlinear_optimizer_for_slam_amd import api
+    name = "/nos_test_%s" % uuid.uuid4().hex
+    try:
+        mp.spawn(_mailbox_lonely_worker, args=(name, str(tmp_path)), nprocs=1, join=True)
+    finally:
+        api.shm_unlink(name)
+    seconds, msg = open(tmp_path / "lonely.txt").read().split("\n")[:2]
+    assert "timed out" in msg and 2.0 < float(seconds) < 15.0, (seconds, msg)
