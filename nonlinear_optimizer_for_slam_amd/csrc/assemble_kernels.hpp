@@ -462,7 +462,9 @@ struct FusedFinal {
   int write_through;               // 1: rows travel as sc1 stores / sc1 loads instead of release / acquire fences
   LmDevice* lm;                    // device-resident loop state: pose source of this launch (null = pose from arguments)
   int lm_step;                     // 1: the finishing workgroup also advances the loop; 0: a separate kernel does
-  Mailbox mail;                    // cross-rank exchange of the sums inside the launch (base == null: none)
+  const Mailbox* mail;             // cross-rank exchange of the sums inside the launch: descriptor in device memory,
+                                   // read by the finishing workgroup only (null: none) — kept out of the kernel
+                                   // arguments proper because every argument stays in scalar registers through the loop
 };
 
 // The exchange itself; called by the first NOUT threads of one workgroup (wave 0 included: NOUT <= 64 and
@@ -693,18 +695,23 @@ __device__ __forceinline__ void finish_in_last_block(const double* partials, con
   double s = 0.0;
   if (col < NOUT) {
     const double* p = partials + col;
-    for (uint32_t r = slice; r < gridDim.x; r += kUnroll * kSlices) {
-      double v[kUnroll];
+    auto sum_rows = [&](auto load) {
+      for (uint32_t r = slice; r < gridDim.x; r += kUnroll * kSlices) {
+        double v[kUnroll];
 #pragma unroll
-      for (int u = 0; u < kUnroll; ++u) {
-        const uint32_t rr = r + u * kSlices;
-        const double* q = p + size_t(rr < gridDim.x ? rr : r) * NOUT;  // clamped address, value masked below
-        const double x = wt ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q;
-        v[u] = rr < gridDim.x ? x : 0.0;
+        for (int u = 0; u < kUnroll; ++u) {
+          const uint32_t rr = r + u * kSlices;
+          const double x = load(p + size_t(rr < gridDim.x ? rr : r) * NOUT);  // clamped address, value masked below
+          v[u] = rr < gridDim.x ? x : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) s += v[u];
       }
-#pragma unroll
-      for (int u = 0; u < kUnroll; ++u) s += v[u];
-    }
+    };
+    if (wt)
+      sum_rows([](const double* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); });
+    else
+      sum_rows([](const double* q) { return *q; });
   }
   red[slice][col] = s;
   __syncthreads();
@@ -715,7 +722,10 @@ __device__ __forceinline__ void finish_in_last_block(const double* partials, con
     for (int sl = 0; sl < kSlices; ++sl) tot += red[sl][threadIdx.x];
   }
   bool exchange_failed = false;
-  if (fin.mail.base != nullptr) tot = mailbox_allreduce<NOUT>(fin.mail, tot, &exchange_failed);  // grid-uniform branch
+  if (fin.mail != nullptr) {  // grid-uniform branch
+    const Mailbox mb = *fin.mail;
+    tot = mailbox_allreduce<NOUT>(mb, tot, &exchange_failed);
+  }
   if (threadIdx.x < NOUT) {
     if (fin.out_dev != nullptr) fin.out_dev[threadIdx.x] = tot;
     if (fin.out_host != nullptr)
@@ -936,40 +946,71 @@ __global__ __launch_bounds__(BLOCK, MINW) void assemble_indexed_kernel(IndexedLa
     for (int k = 0; k < K; ++k) load_voxel_record<T>(table, vid[k] < 0 ? 0 : vid[k], rec[k]);  // id 0 is always readable
   };
 
-  T p_cur[3], p_nxt[3], p_far[3];
-  int32_t v_cur[K], v_nxt[K], v_far[K];
-  T rec_cur[K][12], rec_nxt[K][12];
-  uint32_t c = blockIdx.x;
-  load_point(c, p_cur, v_cur);
-  load_point(c + gridDim.x, p_nxt, v_nxt);
-  load_records(v_cur, rec_cur);
-  for (; c < n_chunks; c += gridDim.x) {
-    load_point(c + 2 * gridDim.x, p_far, v_far);  // stage 1 of chunk c+2
-    load_records(v_nxt, rec_nxt);                   // stage 2 of chunk c+1
+  // Three-stage software pipeline, unrolled three times so that the buffers rotate by NAME instead of by register
+  // copies (a copy of a buffer that is still being loaded forces a wait, and the compiler's conservative waitcnt
+  // placement around loop-carried copies made every iteration wait for the loads it had just issued):
+  //   stage(A, B, C):  issue points+ids of chunk c+2g into C | issue the voxel records of chunk c+g (ids in B) |
+  //                    evaluate chunk c from A (points, ids, records all loaded one / two stages ago)
+  T pt0[3], pt1[3], pt2[3];
+  int32_t id0[K], id1[K], id2[K];
+  T rc0[K][12], rc1[K][12], rc2[K][12];
+  auto evaluate = [&](const T (&p)[3], const int32_t (&vid)[K], const T (&rec)[K][12]) {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      if (v_cur[k] >= 0) {
+      if (vid[k] >= 0) {
         T x[15];
-        x[0] = p_cur[0];
-        x[1] = p_cur[1];
-        x[2] = p_cur[2];
+        x[0] = p[0];
+        x[1] = p[1];
+        x[2] = p[2];
 #pragma unroll
-        for (int m = 0; m < 12; ++m) x[3 + m] = rec_cur[k][m];
+        for (int m = 0; m < 12; ++m) x[3 + m] = rec[k][m];
         Problem::item(x, P, true, acc);
       }
     }
+  };
+  uint32_t c = blockIdx.x;
+  const uint32_t g = gridDim.x;
+  load_point(c, pt0, id0);
+  load_point(c + g, pt1, id1);
+  load_records(id0, rc0);
+  if constexpr (K >= 2) {
+    // two records per point: three record buffers do not fit the register file (fp64 spills, fp32 loses occupancy);
+    // two buffers rotated by copy, scheduling left to the compiler — measured faster for K = 2 (A/B on one box:
+    // fp64 0.143 vs 0.162 ms, fp32 0.064 vs 0.067 ms per 5 M points)
+    for (; c < n_chunks; c += g) {
+      load_point(c + 2 * g, pt2, id2);
+      load_records(id1, rc1);
+      evaluate(pt0, id0, rc0);
 #pragma unroll
-    for (int m = 0; m < 3; ++m) {
-      p_cur[m] = p_nxt[m];
-      p_nxt[m] = p_far[m];
+      for (int m = 0; m < 3; ++m) {
+        pt0[m] = pt1[m];
+        pt1[m] = pt2[m];
+      }
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        id0[k] = id1[k];
+        id1[k] = id2[k];
+#pragma unroll
+        for (int m = 0; m < 12; ++m) rc0[k][m] = rc1[k][m];
+      }
     }
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      v_cur[k] = v_nxt[k];
-      v_nxt[k] = v_far[k];
-#pragma unroll
-      for (int m = 0; m < 12; ++m) rec_cur[k][m] = rec_nxt[k][m];
-    }
+  } else
+  for (; c < n_chunks; c += 3 * g) {
+    load_point(c + 2 * g, pt2, id2);
+    load_records(id1, rc1);
+    __builtin_amdgcn_sched_barrier(0);
+    evaluate(pt0, id0, rc0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_point(c + 3 * g, pt0, id0);
+    load_records(id2, rc2);
+    __builtin_amdgcn_sched_barrier(0);
+    evaluate(pt1, id1, rc1);
+    __builtin_amdgcn_sched_barrier(0);
+    load_point(c + 4 * g, pt1, id1);
+    load_records(id0, rc0);
+    __builtin_amdgcn_sched_barrier(0);
+    evaluate(pt2, id2, rc2);
+    __builtin_amdgcn_sched_barrier(0);
   }
   double dacc[kOut];
 #pragma unroll

@@ -103,6 +103,7 @@ struct nos_ctx {
   size_t shm_bytes = 0;
   double* shm_dev = nullptr;           // its device address (hipHostRegister, mapped)
   unsigned long long* d_round = nullptr;  // device word: exchange rounds completed
+  nos::Mailbox* d_mail = nullptr;         // device copy of the descriptor the kernels read
 };
 
 namespace nosd {
