@@ -117,7 +117,7 @@ int nos_ctx_comm_size(const nos_ctx* ctx); /* 0 if no communicator */
  * them in rank order, so nos_*_accumulate and nos_*_solve return identical bits on every rank with no extra
  * kernel, no RCCL call and no host step per iteration.  This is the reference's "sum the per-thread partials"
  * (MDM/..._analytic_simd.cc:70-75) across processes.  At most 64 ranks; all ranks must issue the same sequence of
- * calls; a rank that never arrives makes the others return NOS_ERR_HIP after 3 s instead of hanging. */
+ * calls; a rank that never arrives makes the others return NOS_ERR_HIP after 8 s instead of hanging. */
 int nos_ctx_comm_init_shm(nos_ctx* ctx, int n_ranks, int rank, const char* shm_name);
 int nos_comm_shm_unlink(const char* shm_name);
 /* Leaves whichever communicator the context has (collective for RCCL); nos_ctx_destroy does it implicitly. */

@@ -440,10 +440,10 @@ constexpr int kLogEntryDoubles = 64;
 // finished its GPU's sums stores them into its own slot followed by a round number (system-scope release), polls the
 // round numbers of all ranks (one lane per rank) and adds the slots in rank order — every rank gets identical bits,
 // with no extra kernel launch, no RCCL call and no host step in the iteration.  Slots are double buffered by round
-// parity: a rank can be at most one round ahead of the slowest reader.  The wait is bounded (kMailboxTimeoutTicks of
+// parity: a rank can be at most one round ahead of the slowest reader.  The wait is bounded (kMailboxTimeoutTicks = 8 s of
 // the 100 MHz wall clock): on a time-out the launch flags an error instead of spinning for ever.
 constexpr int kMailSlotDoubles = 64;                         // one slot: [0..27] sums, [32] round number; 512 bytes
-constexpr unsigned long long kMailboxTimeoutTicks = 300000000ull;  // 3 s
+constexpr unsigned long long kMailboxTimeoutTicks = 800000000ull;  // 8 s
 struct Mailbox {
   double* base;                 // device address of the shared mailbox: [n_ranks][2][kMailSlotDoubles]; null = no exchange
   unsigned long long* round;    // device word: rounds completed by this rank (all ranks run the same sequence)

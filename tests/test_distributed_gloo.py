@@ -192,4 +192,4 @@ def test_mailbox_allreduce_reports_a_missing_peer_instead_of_hanging(tmp_path):
     finally:
         api.shm_unlink(name)
     seconds, msg = open(tmp_path / "lonely.txt").read().split("\n")[:2]
-    assert "timed out" in msg and 2.0 < float(seconds) < 15.0, (seconds, msg)
+    assert "timed out" in msg and 6.0 < float(seconds) < 25.0, (seconds, msg)
