@@ -82,6 +82,20 @@ def cpu_baseline(planes, seconds):
            "sample": "%d full passes over the same %d-correspondence workload, AVX2+FMA fp32 lanes "
                      "(restates ..._analytic_simd_various.cc:1300-1447), %d threads of %d visible cores, reference "
                      "thread partition" % (passes, n, cores, avail)}
+    # the same AVX2 path on ONE thread (SURVEY §8d asks for T = all and T = 1)
+    passes1, t0 = 0, time.perf_counter()
+    while True:
+        oracle.avx_ndt6_accumulate(p32, R, t, LOSS, threads=1)
+        passes1 += 1
+        el1 = time.perf_counter() - t0
+        if el1 >= 0.4 * seconds and passes1 >= 2:
+            break
+    avx["one_thread_value"] = n * passes1 / el1
+    try:
+        with open("/proc/cpuinfo") as f:
+            avx["cpu_model"] = next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
+    except Exception:  # noqa: BLE001
+        avx["cpu_model"] = "unknown"
     del p32
     ns = min(n, 4_000_000)
     sub = np.ascontiguousarray(planes[:, :ns])
@@ -184,7 +198,7 @@ def main():
                         ctx.comm_init_shm_from_torch()
                     else:
                         ctx.comm_init_from_torch()
-                    for _ in range(3):
+                    for _ in range(100):  # many rounds: both parities of the double-buffered mailbox, ranks out of step
                         got = ctx.comm_allreduce([rank + 1.0, 1.0])
                         if abs(got[0] - world * (world + 1) / 2.0) > 1e-12 or abs(got[1] - world) > 1e-12:
                             raise RuntimeError("%s self-test mismatch: %r" % (candidate, got))
