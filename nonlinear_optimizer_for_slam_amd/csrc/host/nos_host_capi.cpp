@@ -4,6 +4,7 @@
 // They exist so the Python test-suite and bench can exercise the C++ host layer; they add no
 // arithmetic of their own.
 #include <cstddef>
+#include <chrono>
 #include <memory>
 #include <vector>
 
@@ -113,6 +114,63 @@ int nos_host_ndt_solve(int dof, size_t n, const double* const planes[15], int lo
     StoreReport(solver->report(), report);
     if (ok) StorePose(pose, t, R);
     return ok ? 1 : 0;
+  } catch (...) {
+    return 0;
+  }
+}
+
+// Wall time of the drop-in call as a user makes it: one solver object, `repeats` cold Solve() calls on the same
+// std::vector<Correspondence> (each: records → device, LM loop, free), and the split Prepare / SolvePrepared.
+// ms_out = {min Solve, mean Solve, min Prepare, min SolvePrepared, iterations of the last solve}.
+int nos_host_ndt_cold_solve_timing(size_t n, const double* const planes[15], int loss_kind, double loss_a, double loss_b,
+                                   int max_iterations, int dtype, int repeats, double ms_out[5]) {
+  namespace mdm = nonlinear_optimizer::mahalanobis_distance_minimizer;
+  try {
+    std::vector<mdm::Correspondence> correspondences(n);
+    for (size_t i = 0; i < n; ++i) {
+      mdm::Correspondence& c = correspondences[i];
+      for (int k = 0; k < 3; ++k) {
+        c.point(k) = planes[k][i];
+        c.ndt.mean(k) = planes[3 + k][i];
+        for (int j = 0; j < 3; ++j) c.ndt.sqrt_information(k, j) = planes[6 + 3 * k + j][i];
+      }
+      c.ndt.is_valid = true;
+    }
+    const int dev = 0;
+    HipOptions hip = MakeHipOptions(dtype, &dev, 1, 0);
+    mdm::MahalanobisDistanceMinimizerHip solver(hip);
+    solver.SetLossFunction(MakeLoss(loss_kind, loss_a, loss_b));
+    const Options options = MakeOptions(max_iterations, 1e-6, 1e-6);
+    using clock = std::chrono::steady_clock;
+    auto ms = [](clock::time_point a, clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    double best = 1e300, sum = 0.0, best_prep = 1e300, best_loop = 1e300;
+    Pose pose = Pose::Identity();
+    if (!solver.Solve(options, correspondences, &pose)) return 0;  // context creation, module load
+    for (int r = 0; r < repeats; ++r) {
+      pose = Pose::Identity();
+      const auto t0 = clock::now();
+      if (!solver.Solve(options, correspondences, &pose)) return 0;
+      const double d = ms(t0, clock::now());
+      best = std::min(best, d);
+      sum += d;
+    }
+    for (int r = 0; r < repeats; ++r) {
+      pose = Pose::Identity();
+      const auto t0 = clock::now();
+      if (!solver.Prepare(correspondences)) return 0;
+      const auto t1 = clock::now();
+      if (!solver.SolvePrepared(options, &pose)) return 0;
+      const auto t2 = clock::now();
+      solver.ReleasePrepared();
+      best_prep = std::min(best_prep, ms(t0, t1));
+      best_loop = std::min(best_loop, ms(t1, t2));
+    }
+    ms_out[0] = best;
+    ms_out[1] = sum / repeats;
+    ms_out[2] = best_prep;
+    ms_out[3] = best_loop;
+    ms_out[4] = solver.report().iterations;
+    return 1;
   } catch (...) {
     return 0;
   }

@@ -631,6 +631,54 @@ int lm_solve(nos_dataset* ds, const Request& rq, const nos_lm_options* opt, doub
 
 // ------------------------------------------------------------------ dataset construction
 
+// Pool limits: at most 8 parked buffers and 16 GiB per device; a parked buffer serves a request if it is large
+// enough and not more than twice (+1 MiB) the size asked for.  The caller has selected the slot's device.
+constexpr size_t kPoolMaxEntries = 8;
+constexpr size_t kPoolMaxBytes = size_t(16) << 30;
+
+int pool_alloc(DeviceSlot& slot, size_t bytes, void** ptr, size_t* capacity) {
+  if (bytes == 0) bytes = 8;
+  int best = -1;
+  for (int i = 0; i < int(slot.pool.size()); ++i) {
+    const size_t have = slot.pool[i].bytes;
+    if (have >= bytes && have <= 2 * bytes + (size_t(1) << 20) && (best < 0 || have < slot.pool[best].bytes)) best = i;
+  }
+  if (best >= 0) {
+    *ptr = slot.pool[best].ptr;
+    *capacity = slot.pool[best].bytes;
+    slot.pool_bytes -= slot.pool[best].bytes;
+    slot.pool.erase(slot.pool.begin() + best);
+    return NOS_OK;
+  }
+  hipError_t e = hipMalloc(ptr, bytes);
+  if (e == hipErrorOutOfMemory && !slot.pool.empty()) {  // give the parked buffers back and try once more
+    for (auto& pe : slot.pool) (void)hipFree(pe.ptr);
+    slot.pool.clear();
+    slot.pool_bytes = 0;
+    e = hipMalloc(ptr, bytes);
+  }
+  if (e != hipSuccess)
+    return fail(e == hipErrorOutOfMemory ? NOS_ERR_OUT_OF_MEMORY : NOS_ERR_HIP, "hipMalloc(%zu bytes) failed: %s", bytes,
+                hipGetErrorString(e));
+  *capacity = bytes;
+  return NOS_OK;
+}
+
+void pool_release(DeviceSlot& slot, void* ptr, size_t capacity) {
+  if (!ptr) return;
+  if (env_int("NOS_POOL", 1) == 0 || capacity > kPoolMaxBytes) {
+    (void)hipFree(ptr);
+    return;
+  }
+  slot.pool.push_back({ptr, capacity});
+  slot.pool_bytes += capacity;
+  while (slot.pool.size() > kPoolMaxEntries || slot.pool_bytes > kPoolMaxBytes) {  // oldest first
+    (void)hipFree(slot.pool.front().ptr);
+    slot.pool_bytes -= slot.pool.front().bytes;
+    slot.pool.erase(slot.pool.begin());
+  }
+}
+
 int alloc_shards(nos_ctx* ctx, nos_dataset* ds) {
   const int n_shards = int(ctx->slots.size());
   const size_t n = ds->n;
@@ -647,7 +695,9 @@ int alloc_shards(nos_ctx* ctx, nos_dataset* ds) {
     sh.layout = make_layout(cnt, ds->n_fields, tile_log2);
     sh.bytes = layout_elems(sh.layout, ds->n_fields) * elem_size(ds->dtype);
     NOS_HIP_CHECK(hipSetDevice(ctx->slots[s].device));
-    NOS_HIP_CHECK(hipMalloc(&sh.data, sh.bytes));
+    int prc = pool_alloc(ctx->slots[s], sh.bytes, &sh.data, &sh.capacity);
+    if (prc != NOS_OK) return prc;
+    sh.pooled = true;
     sh.layout.base = sh.data;
     begin += cnt;
   }
@@ -810,16 +860,26 @@ int create_from_records(nos_ctx* ctx, int kind, size_t n, const void* records, s
     DeviceSlot& slot = ctx->slots[sh.slot];
     const size_t cnt = sh.layout.n;
     hipError_t e = hipSetDevice(slot.device);
-    void* stage[2] = {nullptr, nullptr};
-    hipEvent_t done[2] = {nullptr, nullptr};
-    hipStream_t copy_stream = nullptr;
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking);
-    for (int b = 0; b < 2 && e == hipSuccess; ++b) {
-      e = hipMalloc(&stage[b], chunk_records * stride);
-      if (e == hipSuccess) e = hipEventCreateWithFlags(&done[b], hipEventDisableTiming);
+    // persistent per-device ingestion resources (stream, events, staging buffers sized to what this call needs)
+    const size_t want_stage = std::min(chunk_records, std::max<size_t>(cnt, 1)) * stride;
+    if (e == hipSuccess && slot.copy_stream == nullptr) e = hipStreamCreateWithFlags(&slot.copy_stream, hipStreamNonBlocking);
+    for (int b = 0; b < 2 && e == hipSuccess; ++b)
+      if (slot.ing_done[b] == nullptr) e = hipEventCreateWithFlags(&slot.ing_done[b], hipEventDisableTiming);
+    if (e == hipSuccess && slot.ing_copied == nullptr) e = hipEventCreateWithFlags(&slot.ing_copied, hipEventDisableTiming);
+    if (e == hipSuccess && slot.stage_bytes < want_stage) {
+      for (int b = 0; b < 2; ++b) {
+        if (slot.stage[b]) (void)hipFree(slot.stage[b]);
+        slot.stage[b] = nullptr;
+      }
+      slot.stage_bytes = 0;
+      const size_t grow = std::max(want_stage, size_t(4) << 20);
+      for (int b = 0; b < 2 && e == hipSuccess; ++b) e = hipMalloc(&slot.stage[b], grow);
+      if (e == hipSuccess) slot.stage_bytes = grow;
     }
-    hipEvent_t copied = nullptr;
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&copied, hipEventDisableTiming);
+    void** stage = slot.stage;
+    hipEvent_t* done = slot.ing_done;
+    hipStream_t copy_stream = slot.copy_stream;
+    hipEvent_t copied = slot.ing_copied;
     int buf = 0;
     bool used[2] = {false, false};
     for (size_t first = 0; first < cnt && e == hipSuccess && rc == NOS_OK; first += chunk_records, buf ^= 1) {
@@ -844,15 +904,7 @@ int create_from_records(nos_ctx* ctx, int kind, size_t n, const void* records, s
       rc = (dtype == NOS_F64) ? zero_pad_launch<double>(ds->n_fields, sh.layout, sh.data, slot.stream)
                               : zero_pad_launch<float>(ds->n_fields, sh.layout, sh.data, slot.stream);
     if (e == hipSuccess) e = hipStreamSynchronize(slot.stream);
-    if (copy_stream) {
-      (void)hipStreamSynchronize(copy_stream);
-      (void)hipStreamDestroy(copy_stream);
-    }
-    for (int b = 0; b < 2; ++b) {
-      if (stage[b]) (void)hipFree(stage[b]);
-      if (done[b]) (void)hipEventDestroy(done[b]);
-    }
-    if (copied) (void)hipEventDestroy(copied);
+    if (copy_stream) (void)hipStreamSynchronize(copy_stream);
     if (e != hipSuccess || rc != NOS_OK) {
       nos_dataset_destroy(ds);
       if (rc != NOS_OK) return rc;
@@ -980,6 +1032,17 @@ int nos_ctx_destroy(nos_ctx* ctx) {
     if (s.h_out) (void)hipHostFree(s.h_out);
     if (s.counter) (void)hipFree(s.counter);
     if (s.d_lm) (void)hipFree(s.d_lm);
+    if (s.copy_stream) {
+      (void)hipStreamSynchronize(s.copy_stream);
+      (void)hipStreamDestroy(s.copy_stream);
+    }
+    for (int b = 0; b < 2; ++b) {
+      if (s.stage[b]) (void)hipFree(s.stage[b]);
+      if (s.ing_done[b]) (void)hipEventDestroy(s.ing_done[b]);
+    }
+    if (s.ing_copied) (void)hipEventDestroy(s.ing_copied);
+    for (auto& pe : s.pool) (void)hipFree(pe.ptr);
+    s.pool.clear();
     if (s.h_log) (void)hipHostFree(s.h_log);
     if (s.ev0) (void)hipEventDestroy(s.ev0);
     if (s.ev1) (void)hipEventDestroy(s.ev1);
@@ -1052,7 +1115,15 @@ int nos_dataset_destroy(nos_dataset* ds) {
   if (!ds) return NOS_OK;
   for (Shard& sh : ds->shards) {
     if (sh.data || sh.index || sh.table) (void)hipSetDevice(ds->ctx->slots[sh.slot].device);
-    if (sh.data) (void)hipFree(sh.data);
+    if (sh.data) {
+      // the stream may still be reading the buffer (asynchronous entry points): wait before it is handed on
+      if (sh.pooled) {
+        (void)hipStreamSynchronize(ds->ctx->slots[sh.slot].stream);
+        pool_release(ds->ctx->slots[sh.slot], sh.data, sh.capacity);
+      } else {
+        (void)hipFree(sh.data);
+      }
+    }
     if (sh.index) (void)hipFree(sh.index);
     if (sh.table) (void)hipFree(sh.table);
   }

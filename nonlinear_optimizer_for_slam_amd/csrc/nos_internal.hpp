@@ -80,6 +80,21 @@ struct DeviceSlot {
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
   // per-launch kernel timing (nos_ctx_profile_begin/_end): event pairs recorded on the
   // launch stream around every assemble kernel while profiling is on
+  // Ingestion resources, created on first use and kept (a cold Solve() used to spend ≈ 3 ms creating and freeing
+  // them): copy stream, events, two staging buffers that only grow.
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t ing_done[2] = {nullptr, nullptr};
+  hipEvent_t ing_copied = nullptr;
+  void* stage[2] = {nullptr, nullptr};
+  size_t stage_bytes = 0;
+  // Device-buffer pool for dataset storage: nos_dataset_destroy parks the buffer here, the next dataset of a similar
+  // size takes it over (the reference's outer loop re-Solves up to 10 times with correspondences of similar count).
+  struct PoolEntry {
+    void* ptr;
+    size_t bytes;
+  };
+  std::vector<PoolEntry> pool;
+  size_t pool_bytes = 0;
   std::vector<hipEvent_t> prof_events;
   size_t prof_used = 0;
   bool prof_on = false;
@@ -113,6 +128,8 @@ struct Shard {
   nos::TiledLayout layout{};
   void* data = nullptr;
   size_t bytes = 0;
+  size_t capacity = 0;        // size of the allocation behind `data` (>= bytes when it came from the pool)
+  bool pooled = false;        // data goes back to the slot's pool on destroy
   // voxel-indexed datasets (kKindNdtIndexed): data = 3 point planes; plus
   int32_t* index = nullptr;   // n_slots planes of n_padded voxel ids
   void* table = nullptr;      // [n_voxels][16] voxel records
@@ -212,6 +229,8 @@ inline void fill_loss(const nos_loss* loss, T& la, T& lb, T& lc) {
 }
 
 // nos_core.hip
+int pool_alloc(DeviceSlot& slot, size_t bytes, void** ptr, size_t* capacity);
+void pool_release(DeviceSlot& slot, void* ptr, size_t capacity);
 int env_int(const char* name, int dflt);
 size_t elem_size(int dtype);
 int dataset_new(nos_ctx* ctx, int kind, size_t n, int dtype, nos_dataset** out, nos_dataset** made);
