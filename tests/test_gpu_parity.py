@@ -411,3 +411,71 @@ def test_cpp_class_multi_shard_and_fp32_solve_agree_with_single_shard():
     pa, pb = solvers.Pose(), solvers.Pose()
     assert f32.Solve(solvers.Options(), planes, pa) and f64.Solve(solvers.Options(), planes, pb)
     assert np.max(np.abs(pa.t - pb.t)) < 2e-4 and np.max(np.abs(pa.R - pb.R)) < 2e-4
+
+
+# ---------------------------------------------------------------- more full-size properties (BASELINE.json sizes)
+
+def test_full_size_reprojection_additivity_and_oracle_sample(ctx, oracle):
+    """BASELINE.json configs[2]: 2 M reprojection correspondences, Huber.  Additive over a split, invariant under
+    reversal, and a 250 k slice agrees with the scalar oracle."""
+    n = 2_000_000
+    planes = synth.reproj_planes(n)
+    loss = ("huber", synth.REPROJ_HUBER_THRESHOLD)
+    whole = ReprojDataset.from_planes(ctx, planes, "f64")
+    a_all = whole.accumulate(R_TEST, T_TEST, synth.REPROJ_INTR4, loss)
+    whole.close()
+    parts = np.zeros(28)
+    for sl in (slice(0, 700_001), slice(700_001, n)):
+        ds = ReprojDataset.from_planes(ctx, np.ascontiguousarray(planes[:, sl]), "f64")
+        parts += ds.accumulate(R_TEST, T_TEST, synth.REPROJ_INTR4, loss)
+        ds.close()
+    helpers.assert_normal_equations_close(parts, a_all, 6, 1e-11)
+    rev = ReprojDataset.from_planes(ctx, np.ascontiguousarray(planes[:, ::-1]), "f64")
+    helpers.assert_normal_equations_close(rev.accumulate(R_TEST, T_TEST, synth.REPROJ_INTR4, loss), a_all, 6, 1e-11)
+    rev.close()
+    sub = np.ascontiguousarray(planes[:, :250_000])
+    ds = ReprojDataset.from_planes(ctx, sub, "f64")
+    helpers.assert_normal_equations_close(ds.accumulate(R_TEST, T_TEST, synth.REPROJ_INTR4, loss),
+                                          oracle.reproj_accumulate(sub, R_TEST, T_TEST, synth.REPROJ_INTR4, loss), 6, RTOL_F64)
+    ds.close()
+
+
+def test_full_size_planar_additivity(ctx):
+    """The 3-DoF sums at the configs[1] size: additive over a split and invariant under reversal."""
+    n = 10_000_000
+    planes = synth.ndt_planes(n, 200_000)
+    loss = ("exponential", 1.0, 1.0)
+    R2 = np.array([[np.cos(0.05), -np.sin(0.05)], [np.sin(0.05), np.cos(0.05)]])
+    t2 = np.array([-0.1, 0.05])
+    whole = NdtDataset.from_planes(ctx, planes, "f64")
+    a_all = whole.accumulate3(R2, t2, loss)
+    whole.close()
+    parts = np.zeros(10)
+    for sl in (slice(0, 4_000_003), slice(4_000_003, n)):
+        ds = NdtDataset.from_planes(ctx, np.ascontiguousarray(planes[:, sl]), "f64")
+        parts += ds.accumulate3(R2, t2, loss)
+        ds.close()
+    helpers.assert_normal_equations_close(parts, a_all, 3, 1e-11)
+
+
+def test_full_size_device_loop_equals_host_loop_and_reaches_the_true_pose(ctx):
+    """configs[1] end to end: the device-resident loop and the host loop on the same 10 M-correspondence dataset stop at
+    the same iteration with the same pose, and that pose is the generator's true pose up to the noise floor."""
+    planes = synth.ndt_planes(10_000_000, 200_000)
+    loss = ("exponential", 1.0, 1.0)
+    ds = NdtDataset.from_planes(ctx, planes, "f64")
+    del planes
+    R, t, rep = ds.solve6(np.eye(3), np.zeros(3), loss, max_iterations=100)
+    host = solvers.MahalanobisDistanceMinimizerHip(device_loop=False)
+    host.SetLossFunction(loss)
+    pose = solvers.Pose()
+    opt = solvers.Options()
+    opt.max_iterations = 100
+    assert host.SolveDataset(opt, ds, pose)
+    assert rep["ok"] and rep["iterations"] == host.report.iterations
+    dt, dq = helpers.pose_delta(R.reshape(3, 3), t, pose.R, pose.t)
+    assert dt < 1e-10 and dq < 1e-10, (dt, dq)
+    Rt, tt = synth.true_pose("ndt")
+    dt, dq = helpers.pose_delta(R.reshape(3, 3), t, Rt, tt)
+    assert dt < 5e-4 and dq < 2e-4, (dt, dq)
+    ds.close()
