@@ -433,6 +433,7 @@ constexpr int kLogCost = 46;
 constexpr int kLogIteration = 47;
 constexpr int kLogDone = 48;
 constexpr int kLogOk = 49;
+constexpr int kLogExecuted = 62;  // single-workgroup solve: iterations executed inside the launch
 constexpr int kLogEntryDoubles = 64;
 
 // In-kernel all-reduce of the per-GPU sums for one-process-per-GPU runs on one node (nos_ctx_comm_init_shm): a mailbox
@@ -866,6 +867,113 @@ __global__ __launch_bounds__(BLOCK, MINW) void assemble_kernel(TiledLayout L,
   }
 #endif
   if (fin.counter != nullptr) finish_in_last_block<kOut, BLOCK>(partials, fin, t_start);
+}
+
+// ---------------------------------------------------------------- whole solve in one workgroup (small problems)
+//
+// At the reference's own test sizes (630 reprojection points, ≈ 2.9 k NDT correspondences) an LM iteration through the
+// grid kernel costs ≈ 11-12 µs, nearly all of it launch, hand-off and dispatch latency.  Below kSingleBlockMaxElements
+// plane-elements the whole loop runs inside ONE workgroup and ONE launch instead: the data (≤ 1 MB) stays in L2, the sums are
+// reduced inside the block, one lane runs the same nos_host::LmAdvance* loop body on a state kept in LDS, and the
+// next iteration starts after one barrier — no grid-wide hand-off, nothing to wait for, no way to hang.
+// One CU evaluates a 512-correspondence NDT chunk in ≈ 0.9 µs, so the single-workgroup form only pays while the whole
+// pass stays below the ≈ 6 µs that a launch with its hand-off costs: measured 11.3 → 5.3 µs per iteration at 630
+// reprojection points, but no gain at 2 900 NDT correspondences (6 chunks) — hence a budget in plane-elements.
+constexpr size_t kSingleBlockMaxElements = size_t(1024) * 15;  // n × fields: 1024 NDT or 3072 reprojection correspondences
+
+template <typename Problem, typename T, int BLOCK, bool NT = false>
+__global__ __launch_bounds__(BLOCK) void solve_single_block_kernel(TiledLayout L, typename Problem::Params P,
+                                                                  uint32_t n_chunks, LmDevice* lm,
+                                                                  double* __restrict__ cost_history, int history_capacity,
+                                                                  double* entry_host, unsigned long long* seq_host,
+                                                                  unsigned long long seq) {
+  constexpr int kF = Problem::kFields;
+  constexpr int kOut = Problem::kOut;
+  const T* __restrict__ base = static_cast<const T*>(L.base);
+  __shared__ double s_lm_raw[(sizeof(LmDevice) + 7) / 8];  // raw storage: the struct has default member initialisers
+  LmDevice& s_lm = *reinterpret_cast<LmDevice*>(s_lm_raw);
+  __shared__ double s_sum[kOut];
+  if (threadIdx.x == 0) s_lm = *lm;
+  __syncthreads();
+  int executed = 0;
+  while (s_lm.st.done == 0) {  // block-uniform: every thread reads the same LDS word after a barrier
+    set_pose(P, &s_lm);
+    T acc[kOut];
+#pragma unroll
+    for (int k = 0; k < kOut; ++k) acc[k] = T(0);
+    // several chunks per round, all their loads in flight before the first item is evaluated: with one workgroup there
+    // are no other waves to hide the L2 latency behind
+    constexpr uint32_t kRound = (kF * sizeof(T) > 64) ? 2 : 4;  // 15 fp64 planes: two chunks fill the register file
+    for (uint32_t c = 0; c < n_chunks; c += kRound) {
+      T x[kRound][kF][1];
+      uint64_t i0[kRound];
+#pragma unroll
+      for (uint32_t u = 0; u < kRound; ++u) {
+        const uint32_t cu = (c + u < n_chunks) ? c + u : c;  // clamped: re-reads chunk c, masked out below
+        i0[u] = uint64_t(cu) * BLOCK + threadIdx.x;
+        const uint64_t off = (i0[u] >> L.tile_shift) * L.tile_stride + (i0[u] & L.tile_mask);
+#pragma unroll
+        for (int f = 0; f < kF; ++f) load_items<T, 1, NT>(base + off + uint64_t(f) * L.field_stride, x[u][f]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (uint32_t u = 0; u < kRound; ++u) {
+        if (c + u < n_chunks) {  // block-uniform
+          T xi[kF];
+#pragma unroll
+          for (int f = 0; f < kF; ++f) xi[f] = x[u][f][0];
+          Problem::item(xi, P, i0[u] < L.n, acc);
+        }
+      }
+    }
+    double dacc[kOut];
+#pragma unroll
+    for (int k = 0; k < kOut; ++k) dacc[k] = double(acc[k]);
+    block_reduce_store<kOut, BLOCK>(dacc, s_sum, false);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double out[kOut];
+#pragma unroll
+      for (int k = 0; k < kOut; ++k) out[k] = s_sum[k];
+      if (cost_history != nullptr && executed < history_capacity)
+        __hip_atomic_store(cost_history + executed, out[kOut - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if constexpr (kOut == 28)
+        nos_host::LmAdvance6(s_lm.settings, out, &s_lm.st);
+      else
+        nos_host::LmAdvance3(s_lm.settings, out, &s_lm.st);
+    }
+    ++executed;
+    __syncthreads();
+  }
+  if (threadIdx.x < kOut && entry_host != nullptr && executed > 0)
+    __hip_atomic_store(entry_host + kLogOut + threadIdx.x, s_sum[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (threadIdx.x == 0) {
+    const nos_host::LmState st = s_lm.st;
+    lm->st = st;
+    if (entry_host != nullptr) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k)
+        __hip_atomic_store(entry_host + kLogR + k, st.R[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        __hip_atomic_store(entry_host + kLogT + k, st.t[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(entry_host + kLogLambda, st.lambda, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(entry_host + kLogPrevCost, st.previous_cost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(entry_host + kLogCost, st.cost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(entry_host + kLogIteration, double(st.iteration), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(entry_host + kLogDone, double(st.done), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(entry_host + kLogOk, double(st.ok), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(entry_host + kLogExecuted, double(executed), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  if (threadIdx.x < kWave) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0 && seq_host != nullptr) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(seq_host, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
 
 // ---------------------------------------------------------------- voxel-indexed variant

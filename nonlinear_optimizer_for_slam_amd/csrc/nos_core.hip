@@ -163,18 +163,43 @@ int launch_by_variant(int variant, int blocks_per_cu, int num_cus, const nos::Ti
   return fail(NOS_ERR_INVALID_ARGUMENT, "bad variant");
 }
 
+// Arguments of the single-workgroup whole-solve kernel (small problems, see nos::solve_single_block_kernel).
+struct SingleBlockArgs {
+  nos::LmDevice* lm;
+  double* history;  // device address of the pinned cost history (may be null)
+  int history_capacity;
+  double* entry;    // device address of the pinned log entry
+  unsigned long long* seq_host;
+  unsigned long long seq;
+};
+
+template <typename Problem, typename T>
+int launch_single(const nos::TiledLayout& L, const typename Problem::Params& P, const SingleBlockArgs& a, hipStream_t stream) {
+  constexpr int kBlock = 512;
+  if (L.n_padded % kBlock != 0) return fail(NOS_ERR_INVALID_ARGUMENT, "n_padded %% 512 != 0");
+  const uint32_t n_chunks = uint32_t((std::max<uint64_t>(L.n, 1) + kBlock - 1) / kBlock);  // pads beyond are never read
+  hipLaunchKernelGGL((nos::solve_single_block_kernel<Problem, T, kBlock>), dim3(1), dim3(kBlock), 0, stream, L, P, n_chunks, a.lm,
+                     a.history, a.history_capacity, a.entry, a.seq_host, a.seq);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(NOS_ERR_HIP, "single-workgroup solve launch failed: %s", hipGetErrorString(e));
+  return NOS_OK;
+}
+
 template <template <typename, int> class ProblemT, typename T, typename ParamsT>
 int launch_by_loss(int loss_kind, int variant, int blocks_per_cu, int num_cus,
                    const nos::TiledLayout& L, const ParamsT& P, bool nt, double* partials,
-                   const nos::FusedFinal& fin, hipStream_t stream, int* rows_out) {
+                   const nos::FusedFinal& fin, hipStream_t stream, int* rows_out, const SingleBlockArgs* single = nullptr) {
   switch (loss_kind) {
     case NOS_LOSS_NONE:
+      if (single) return launch_single<ProblemT<T, nos::kLossNone>, T>(L, P, *single, stream);
       return launch_by_variant<ProblemT<T, nos::kLossNone>, T>(variant, blocks_per_cu, num_cus, L, P, nt, partials,
                                                                fin, stream, rows_out);
     case NOS_LOSS_EXPONENTIAL:
+      if (single) return launch_single<ProblemT<T, nos::kLossExponential>, T>(L, P, *single, stream);
       return launch_by_variant<ProblemT<T, nos::kLossExponential>, T>(variant, blocks_per_cu, num_cus, L, P, nt,
                                                                       partials, fin, stream, rows_out);
     case NOS_LOSS_HUBER:
+      if (single) return launch_single<ProblemT<T, nos::kLossHuber>, T>(L, P, *single, stream);
       return launch_by_variant<ProblemT<T, nos::kLossHuber>, T>(variant, blocks_per_cu, num_cus, L, P, nt, partials,
                                                                 fin, stream, rows_out);
   }
@@ -202,7 +227,8 @@ bool use_nontemporal(const nos_dataset* ds, const Shard& sh) {
 }
 
 int launch_assemble_raw(const nos_dataset* ds, const Shard& sh, const Request& rq, double* partials,
-                        const nos::FusedFinal& fin, hipStream_t stream, int* rows_out);
+                        const nos::FusedFinal& fin, hipStream_t stream, int* rows_out,
+                        const SingleBlockArgs* single = nullptr);
 
 // Launches the assemble kernel; with profiling on, brackets it with an event pair on the
 // same stream so its device duration can be read back later without perturbing the loop.
@@ -223,7 +249,7 @@ int launch_assemble(const nos_dataset* ds, const Shard& sh, const Request& rq, d
 }
 
 int launch_assemble_raw(const nos_dataset* ds, const Shard& sh, const Request& rq, double* partials,
-                        const nos::FusedFinal& fin, hipStream_t stream, int* rows_out) {
+                        const nos::FusedFinal& fin, hipStream_t stream, int* rows_out, const SingleBlockArgs* single) {
   if (ds->kind == kKindNdtIndexed) return launch_indexed(ds, sh, rq, partials, fin, stream, rows_out);
   const nos_ctx* ctx = ds->ctx;
   const DeviceSlot& slot = ctx->slots[sh.slot];
@@ -237,14 +263,14 @@ int launch_assemble_raw(const nos_dataset* ds, const Shard& sh, const Request& r
       for (int k = 0; k < 3; ++k) P.t[k] = rq.t[k];
       fill_loss(&rq.loss, P.la, P.lb, P.lc);
       return launch_by_loss<nos::Ndt6Problem, double>(rq.loss_kind, variant, bpc, slot.num_cus, sh.layout, P, nt,
-                                                      partials, fin, stream, rows_out);
+                                                      partials, fin, stream, rows_out, single);
     }
     nos::Ndt6Params<float> P;
     for (int k = 0; k < 9; ++k) P.R[k] = float(rq.R[k]);
     for (int k = 0; k < 3; ++k) P.t[k] = float(rq.t[k]);
     fill_loss(&rq.loss, P.la, P.lb, P.lc);
     return launch_by_loss<nos::Ndt6Problem, float>(rq.loss_kind, variant, bpc, slot.num_cus, sh.layout, P, nt,
-                                                   partials, fin, stream, rows_out);
+                                                   partials, fin, stream, rows_out, single);
   }
   if (rq.problem == 3) {
     if (ds->dtype == NOS_F64) {
@@ -253,14 +279,14 @@ int launch_assemble_raw(const nos_dataset* ds, const Shard& sh, const Request& r
       for (int k = 0; k < 2; ++k) P.t2[k] = rq.t[k];
       fill_loss(&rq.loss, P.la, P.lb, P.lc);
       return launch_by_loss<nos::Ndt3Problem, double>(rq.loss_kind, variant, bpc, slot.num_cus, sh.layout, P, nt,
-                                                      partials, fin, stream, rows_out);
+                                                      partials, fin, stream, rows_out, single);
     }
     nos::Ndt3Params<float> P;
     for (int k = 0; k < 4; ++k) P.R2[k] = float(rq.R[k]);
     for (int k = 0; k < 2; ++k) P.t2[k] = float(rq.t[k]);
     fill_loss(&rq.loss, P.la, P.lb, P.lc);
     return launch_by_loss<nos::Ndt3Problem, float>(rq.loss_kind, variant, bpc, slot.num_cus, sh.layout, P, nt,
-                                                   partials, fin, stream, rows_out);
+                                                   partials, fin, stream, rows_out, single);
   }
   if (ds->dtype == NOS_F64) {
     nos::ReprojParams<double> P;
@@ -273,7 +299,7 @@ int launch_assemble_raw(const nos_dataset* ds, const Shard& sh, const Request& r
     P.min_depth = rq.min_depth;
     fill_loss(&rq.loss, P.la, P.lb, P.lc);
     return launch_by_loss<nos::ReprojProblem, double>(rq.loss_kind, variant, bpc, slot.num_cus, sh.layout, P, nt,
-                                                      partials, fin, stream, rows_out);
+                                                      partials, fin, stream, rows_out, single);
   }
   nos::ReprojParams<float> P;
   for (int k = 0; k < 9; ++k) P.R[k] = float(rq.R[k]);
@@ -285,7 +311,7 @@ int launch_assemble_raw(const nos_dataset* ds, const Shard& sh, const Request& r
   P.min_depth = float(rq.min_depth);
   fill_loss(&rq.loss, P.la, P.lb, P.lc);
   return launch_by_loss<nos::ReprojProblem, float>(rq.loss_kind, variant, bpc, slot.num_cus, sh.layout, P, nt,
-                                                   partials, fin, stream, rows_out);
+                                                   partials, fin, stream, rows_out, single);
 }
 
 int launch_final(int n_out, const double* partials, int rows, double* out, hipStream_t stream) {
@@ -545,6 +571,42 @@ int lm_solve(nos_dataset* ds, const Request& rq, const nos_lm_options* opt, doub
 
   const unsigned long long base_seq = slot.seq;
   unsigned long long* seq_dev = reinterpret_cast<unsigned long long*>(slot.h_out_dev + kSeqSlot);
+  // Small problems: the whole loop in one workgroup and one launch (see nos::solve_single_block_kernel)
+  if (ds->kind != kKindNdtIndexed && !with_comm && ctx->shm_dev == nullptr && opt->max_iterations > 0 &&
+      sh.layout.n * size_t(ds->n_fields) <= nos::kSingleBlockMaxElements && env_int("NOS_LM_SINGLE", 1) != 0 &&
+      (opt->cost_history == nullptr || opt->max_iterations <= kHistCapacity)) {
+    SingleBlockArgs single{slot.d_lm, opt->cost_history ? slot.h_hist_dev : nullptr, kHistCapacity, slot.h_log_dev, seq_dev,
+                           ++slot.seq};
+    int rows = 0;
+    int rc = launch_assemble_raw(ds, sh, rq, slot.partials, nos::FusedFinal{}, slot.stream, &rows, &single);
+    if (rc != NOS_OK) return rc;
+    rc = wait_for_sequence(slot, single.seq);
+    if (rc != NOS_OK) return rc;
+    const double* e = slot.h_log;
+    for (int k = 0; k < 9; ++k) st.R[k] = e[nos::kLogR + k];
+    for (int k = 0; k < 3; ++k) st.t[k] = e[nos::kLogT + k];
+    st.lambda = e[nos::kLogLambda];
+    st.previous_cost = e[nos::kLogPrevCost];
+    st.cost = e[nos::kLogCost];
+    st.iteration = int(e[nos::kLogIteration]);
+    st.done = int(e[nos::kLogDone]);
+    st.ok = int(e[nos::kLogOk]);
+    const int executed = int(e[nos::kLogExecuted]);
+    if (opt->cost_history != nullptr)
+      for (int k = 0; k < executed && k < opt->max_iterations; ++k) opt->cost_history[k] = slot.h_hist[k];
+    for (int k = 0; k < nR; ++k) R[k] = st.R[k];
+    for (int k = 0; k < nt; ++k) t[k] = st.t[k];
+    if (report) {
+      report->iterations = st.iteration;
+      report->ok = st.ok;
+      report->launches = 1;
+      report->reserved = 0;
+      report->printed_cost = st.previous_cost;
+      report->last_cost = st.cost;
+      report->final_lambda = st.lambda;
+    }
+    return NOS_OK;
+  }
   int launched = 0, completed = 0;
   auto launch_one = [&]() -> int {
     double* entry = slot.h_log_dev + size_t(launched % kLogSlots) * nos::kLogEntryDoubles;
@@ -973,6 +1035,8 @@ int nos_ctx_create(const int* device_ids, int n_devices, nos_ctx** out_ctx) {
     if (e == hipSuccess) e = hipHostMalloc(&s.h_log, log_bytes, hipHostMallocMapped);
     if (e == hipSuccess) memset(s.h_log, 0, log_bytes);
     if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&s.h_log_dev), s.h_log, 0);
+    if (e == hipSuccess) e = hipHostMalloc(&s.h_hist, sizeof(double) * kHistCapacity, hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&s.h_hist_dev), s.h_hist, 0);
     if (e == hipSuccess) e = hipMalloc(&s.counter, 2048);  // top ticket + 8 group tickets, 128 bytes apart
     if (e == hipSuccess) e = hipMemset(s.counter, 0, 2048);
     if (e == hipSuccess) e = hipEventCreate(&s.ev0);
@@ -1044,6 +1108,7 @@ int nos_ctx_destroy(nos_ctx* ctx) {
     for (auto& pe : s.pool) (void)hipFree(pe.ptr);
     s.pool.clear();
     if (s.h_log) (void)hipHostFree(s.h_log);
+    if (s.h_hist) (void)hipHostFree(s.h_hist);
     if (s.ev0) (void)hipEventDestroy(s.ev0);
     if (s.ev1) (void)hipEventDestroy(s.ev1);
     if (s.ev2) (void)hipEventDestroy(s.ev2);

@@ -61,6 +61,7 @@ enum DatasetKind { kKindNdt = 1, kKindReproj = 2, kKindNdtIndexed = 3 };
 
 constexpr int kMaxPartialRows = 8192;  // upper bound on grid size of the assemble kernel
 constexpr int kMaxOut = 28;
+constexpr int kHistCapacity = 4096;     // iterations whose cost the single-workgroup solve can report
 constexpr int kLogSlots = 64;          // ring of loop log entries; bounds the number of launches in flight
 
 struct DeviceSlot {
@@ -77,6 +78,8 @@ struct DeviceSlot {
   nos::LmDevice* d_lm = nullptr;   // device-resident loop state (nos_*_solve)
   double* h_log = nullptr;         // pinned, device-mapped ring of per-iteration log entries [kLogSlots][kLogEntryDoubles]
   double* h_log_dev = nullptr;
+  double* h_hist = nullptr;        // pinned, device-mapped cost history of the single-workgroup solve [kHistCapacity]
+  double* h_hist_dev = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
   // per-launch kernel timing (nos_ctx_profile_begin/_end): event pairs recorded on the
   // launch stream around every assemble kernel while profiling is on

@@ -212,3 +212,60 @@ def test_cpp_classes_use_the_device_loop_by_default_and_agree_with_the_host_loop
     dt, dq = helpers.pose_delta(res[True][0], res[True][1], res[False][0], res[False][1])
     assert dt < 1e-10 and dq < 1e-10
     assert res[True][3] == pytest.approx(res[False][3], rel=1e-10)
+
+
+# ---------------------------------------------------------------- whole solve in one workgroup (small problems)
+
+@pytest.mark.parametrize("n", [1, 630, 1024])
+@pytest.mark.parametrize("loss", [EXP, ("huber", 0.7)])
+def test_single_workgroup_solve_equals_the_launch_per_iteration_loop(ctx, oracle, n, loss):
+    """Up to 1024 NDT correspondences nos_ndt6_solve runs the whole loop inside one workgroup (one launch).  Same loop body,
+    same data: iterations, costs and pose must match the launch-per-iteration form (NOS_LM_SINGLE=0) to the last bits
+    that the different summation order allows, and the oracle's loop."""
+    planes = synth.ndt_planes(n, max(1, n // 30))
+    ds = NdtDataset.from_planes(ctx, planes, "f64")
+    one = ds.solve6(np.eye(3), np.zeros(3), loss, max_iterations=60)
+    assert one[2]["launches"] == 1
+    os.environ["NOS_LM_SINGLE"] = "0"
+    try:
+        many = ds.solve6(np.eye(3), np.zeros(3), loss, max_iterations=60)
+    finally:
+        del os.environ["NOS_LM_SINGLE"]
+    assert many[2]["launches"] > 1 or many[2]["iterations"] == 0
+    want = oracle.ndt6_solve(planes, np.zeros(3), np.eye(3), loss=loss, max_iterations=60, linear_solver=1)
+    if n >= 630:   # tiny systems are rank deficient: only the two GPU forms are compared there
+        assert one[2]["iterations"] == many[2]["iterations"] == want["iterations"]
+        dt, dq = helpers.pose_delta(one[0].reshape(3, 3), one[1], want["R"], want["t"])
+        assert dt < 1e-8 and dq < 1e-8, (dt, dq)
+        assert len(one[2]["cost_history"]) == len(many[2]["cost_history"])
+        np.testing.assert_allclose(one[2]["cost_history"], many[2]["cost_history"], rtol=1e-9)
+    assert one[2]["ok"] == many[2]["ok"]
+    if one[2]["ok"]:
+        dt, dq = helpers.pose_delta(one[0].reshape(3, 3), one[1], many[0].reshape(3, 3), many[1])
+        assert dt < 1e-8 and dq < 1e-8, (dt, dq)
+    ds.close()
+
+
+def test_single_workgroup_reprojection_known_answer_and_planar(ctx, oracle):
+    """The reference's reprojection golden (630 points, `COST: 2.33228e-11, iter: 6`) runs in the single-workgroup form
+    by default; so does a small planar solve."""
+    planes, intr, Rt, tt = helpers.reference_reprojection_scene()
+    ds = ReprojDataset.from_planes(ctx, planes, "f64")
+    intr4 = np.array([1.0 / intr[0], 1.0 / intr[1], intr[2], intr[3]])
+    R, t, rep = ds.solve(np.eye(3), np.zeros(3), intr4, EXP, max_iterations=100)
+    assert rep["launches"] == 1 and rep["iterations"] == 6 and "%.5g" % rep["printed_cost"] == "2.3323e-11"
+    inv = solvers.Pose(R.reshape(3, 3), t).inverse()
+    np.testing.assert_allclose(inv.t, tt, atol=5e-7)
+    ds.close()
+    planes = synth.ndt_planes(900, 40)
+    want = oracle.ndt3_solve(planes, np.zeros(3), np.eye(3), loss=EXP, max_iterations=100)
+    ds = NdtDataset.from_planes(ctx, planes, "f32")
+    ds64 = NdtDataset.from_planes(ctx, planes, "f64")
+    R2, t2, rep = ds64.solve3(np.eye(2), np.zeros(2), EXP, max_iterations=100)
+    assert rep["launches"] == 1 and rep["iterations"] == want["iterations"]
+    np.testing.assert_allclose(t2, want["t"][:2], atol=1e-9)
+    R2f, t2f, repf = ds.solve3(np.eye(2), np.zeros(2), EXP, max_iterations=100)
+    assert repf["launches"] == 1
+    np.testing.assert_allclose(t2f, want["t"][:2], atol=2e-4)
+    ds.close()
+    ds64.close()
