@@ -15,8 +15,10 @@ int nos_ndt_map_create(nos_ctx* ctx, size_t n_voxels, const double* means_xyz, c
   if (n_voxels >= 0xFFFFFFFFull) return fail(NOS_ERR_UNSUPPORTED, "too many voxels");
   const double cell = std::sqrt(search_radius_sq);
   const double inv_cell = 1.0 / cell;
-  // bucket the valid voxels by grid cell (std::map keeps cells in key order → deterministic layout)
-  std::map<uint64_t, std::vector<uint32_t>> cells;
+  // bucket the valid voxels by grid cell: sort (cell key, voxel index) pairs — cells in key order, voxels of a cell in
+  // index order (deterministic layout; a sorted vector instead of a std::map of vectors: 5-10x less host time at 10^5+ voxels)
+  std::vector<std::pair<uint64_t, uint32_t>> keyed;
+  keyed.reserve(n_voxels);
   for (size_t v = 0; v < n_voxels; ++v) {
     if (valid && !valid[v]) continue;  // `if (!ndt.is_valid) continue;` of the reference's matcher
     const double* m = means_xyz + 3 * v;
@@ -27,20 +29,36 @@ int nos_ndt_map_create(nos_ctx* ctx, size_t n_voxels, const double* means_xyz, c
     const int64_t lim = (1 << 20) - 2;
     if (std::llabs(ix) > lim || std::llabs(iy) > lim || std::llabs(iz) > lim)
       return fail(NOS_ERR_UNSUPPORTED, "voxel %zu lies outside the addressable grid", v);
-    cells[nos::pack_cell(ix, iy, iz)].push_back(uint32_t(v));
+    keyed.emplace_back(nos::pack_cell(ix, iy, iz), uint32_t(v));
+  }
+  std::sort(keyed.begin(), keyed.end());
+  struct CellRun {
+    uint64_t key;
+    uint32_t first, count;  // range of `keyed`
+  };
+  std::vector<CellRun> cells;
+  for (size_t i = 0; i < keyed.size();) {
+    size_t j = i;
+    while (j < keyed.size() && keyed[j].first == keyed[i].first) ++j;
+    cells.push_back({keyed[i].first, uint32_t(i), uint32_t(j - i)});
+    i = j;
   }
   size_t table_size = 16;
   while (table_size < 2 * cells.size() + 1) table_size <<= 1;
   std::vector<uint64_t> keys(table_size, nos::kEmptyCell);
   std::vector<uint32_t> starts(table_size, 0), counts(table_size, 0), orig;
   std::vector<double> mean_sorted, s_sorted;
-  for (const auto& kv : cells) {
-    uint32_t h = nos::hash_cell(kv.first) & uint32_t(table_size - 1);
+  orig.reserve(keyed.size());
+  mean_sorted.reserve(keyed.size() * 3);
+  s_sorted.reserve(keyed.size() * 9);
+  for (const CellRun& cr : cells) {
+    uint32_t h = nos::hash_cell(cr.key) & uint32_t(table_size - 1);
     while (keys[h] != nos::kEmptyCell) h = (h + 1) & uint32_t(table_size - 1);
-    keys[h] = kv.first;
+    keys[h] = cr.key;
     starts[h] = uint32_t(orig.size());
-    counts[h] = uint32_t(kv.second.size());
-    for (uint32_t v : kv.second) {
+    counts[h] = cr.count;
+    for (uint32_t q = cr.first; q < cr.first + cr.count; ++q) {
+      const uint32_t v = keyed[q].second;
       orig.push_back(v);
       for (int k = 0; k < 3; ++k) mean_sorted.push_back(means_xyz[3 * size_t(v) + k]);
       for (int k = 0; k < 9; ++k) s_sorted.push_back(sqrt_infos[9 * size_t(v) + k]);
@@ -58,9 +76,9 @@ int nos_ndt_map_create(nos_ctx* ctx, size_t n_voxels, const double* means_xyz, c
       c[1] = int64_t((key >> 21) & 0x1FFFFFull) - bias;
       c[2] = int64_t(key & 0x1FFFFFull) - bias;
     };
-    for (const auto& kv : cells) {
+    for (const CellRun& cr : cells) {
       int64_t c[3];
-      unpack(kv.first, c);
+      unpack(cr.key, c);
       for (int k = 0; k < 3; ++k) {
         mn[k] = std::min(mn[k], c[k]);
         mx[k] = std::max(mx[k], c[k]);
@@ -75,12 +93,12 @@ int nos_ndt_map_create(nos_ctx* ctx, size_t n_voxels, const double* means_xyz, c
     if (total <= double(size_t(1) << 26)) {  // ≤ 64 M cells = 256 MB of offsets; beyond that the hash table serves
       const size_t n_cells = size_t(dim[0]) * size_t(dim[1]) * size_t(dim[2]);
       dense_begin.assign(n_cells + 1, 0);
-      // std::map iterates the packed keys in (x, y, z) lexicographic order = dense index order = record order
-      for (const auto& kv : cells) {
+      // ascending packed keys = (x, y, z) lexicographic order = dense index order = record order
+      for (const CellRun& cr : cells) {
         int64_t c[3];
-        unpack(kv.first, c);
+        unpack(cr.key, c);
         const size_t idx = (size_t(c[0] - lo[0]) * size_t(dim[1]) + size_t(c[1] - lo[1])) * size_t(dim[2]) + size_t(c[2] - lo[2]);
-        dense_begin[idx + 1] = uint32_t(kv.second.size());
+        dense_begin[idx + 1] = cr.count;
       }
       for (size_t c = 0; c < n_cells; ++c) dense_begin[c + 1] += dense_begin[c];
       records.resize(orig.size() * 4);
