@@ -12,19 +12,36 @@ namespace nonlinear_optimizer {
 
 namespace {
 
+// Contexts (stream, pinned blocks, workspaces, buffer pool) are cached per device list for the life of the process:
+// the reference's callers construct a solver object per optimisation call (tests/simple_optimization_test.cc builds
+// one inside every OptimizePose* function), and creating a context costs ≈ 1.5 ms — more than a whole small Solve().
+// The cache is deliberately never destroyed at exit (HIP may already be gone during static destruction);
+// ReleaseHipRuntimes() drops it explicitly.
 std::mutex g_runtime_mutex;
-std::map<std::vector<int>, std::weak_ptr<HipRuntime>> g_runtimes;
+using RuntimeCache = std::map<std::vector<int>, std::shared_ptr<HipRuntime>>;
+RuntimeCache& Runtimes() {
+  static RuntimeCache* cache = new RuntimeCache();
+  return *cache;
+}
 
 std::shared_ptr<HipRuntime> AcquireRuntime(const std::vector<int>& device_ids) {
   std::lock_guard<std::mutex> lock(g_runtime_mutex);
-  auto it = g_runtimes.find(device_ids);
-  if (it != g_runtimes.end()) {
-    if (auto alive = it->second.lock()) return alive;
-  }
+  RuntimeCache& cache = Runtimes();
+  auto it = cache.find(device_ids);
+  if (it != cache.end() && it->second->status() == NOS_OK) return it->second;
   auto fresh = std::make_shared<HipRuntime>(device_ids);
-  g_runtimes[device_ids] = fresh;
+  if (fresh->status() == NOS_OK) cache[device_ids] = fresh;  // a failed context (no device) is not cached: retried next time
   return fresh;
 }
+
+}  // namespace
+
+void ReleaseHipRuntimes() {
+  std::lock_guard<std::mutex> lock(g_runtime_mutex);
+  Runtimes().clear();
+}
+
+namespace {
 
 void ReportFailure(const char* where, int status) {
   std::cerr << "[nos-hip] " << where << " failed: " << nos_status_string(status) << " — " << nos_last_error()

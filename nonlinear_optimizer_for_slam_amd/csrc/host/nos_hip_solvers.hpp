@@ -61,6 +61,10 @@ class HipRuntime {
   int status_{0};
 };
 
+// Solver objects share one cached context per device list for the life of the process (creating one costs more than
+// a small Solve()); this drops the cache — e.g. before unloading the library.  Solvers alive at that time keep theirs.
+void ReleaseHipRuntimes();
+
 // Recovers the POD loss descriptor the kernels need from a host LossFunction object whose
 // parameters are private (NO/loss_function.h:43-46,74-76): dynamic_cast to the two known
 // classes, then probe Evaluate().  nullptr → NOS_LOSS_NONE.  Unknown subclass → false.
