@@ -479,3 +479,30 @@ def test_full_size_device_loop_equals_host_loop_and_reaches_the_true_pose(ctx):
     dt, dq = helpers.pose_delta(R.reshape(3, 3), t, Rt, tt)
     assert dt < 5e-4 and dq < 2e-4, (dt, dq)
     ds.close()
+
+
+def test_repeated_cold_solves_do_not_leak_device_memory():
+    """The buffer pool parks at most 8 buffers per device: 300 cold Solve() calls of changing size must leave the free
+    device memory where a handful of calls left it."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("torch cannot see the GPU on this box (environment): no mem_get_info")
+    solver = solvers.MahalanobisDistanceMinimizerHip()
+    solver.SetLossFunction(("exponential", 1.0, 1.0))
+    sizes = [3_000, 50_000, 20_000, 120_000, 7_000, 400_000]
+    cache = {n: synth.ndt_planes(n, max(10, n // 50)) for n in sizes}
+    opt = solvers.Options()
+    opt.max_iterations = 5
+
+    def sweep(rounds):
+        for r in range(rounds):
+            for n in sizes:
+                assert solver.Solve(opt, cache[n], solvers.Pose())
+
+    sweep(3)
+    torch.cuda.synchronize()
+    free_before, _ = torch.cuda.mem_get_info()
+    sweep(50)
+    torch.cuda.synchronize()
+    free_after, _ = torch.cuda.mem_get_info()
+    assert free_before - free_after < (256 << 20), (free_before, free_after)
