@@ -290,3 +290,24 @@ def test_reprojection_reference_test_wall_time(capsys):
     with capsys.disabled():
         print("\n[reproj wrapper] 630 points, %d LM iterations, cold Solve(): %.3f ms" % (solver.report.iterations, 1e3 * best))
     assert solver.report.iterations == 6 and best < 0.005
+
+
+@pytest.mark.parametrize("device_loop", [True, False])
+@pytest.mark.parametrize("n", [500, 40_000])
+def test_non_finite_input_makes_solve_fail_cleanly(device_loop, n):
+    """A NaN coordinate poisons the sums; Eigen's ldlt() in the reference would hand a NaN pose back with `true`.  Here
+    the damped solve sees a non-positive / non-finite pivot and Solve() returns false with the pose untouched — in the
+    single-workgroup form, the launch-per-iteration form and the host loop alike."""
+    planes = synth.ndt_planes(n, max(10, n // 40)).copy()
+    planes[1, n // 2] = np.nan
+    solver = solvers.MahalanobisDistanceMinimizerHip(device_loop=device_loop)
+    solver.SetLossFunction(EXP)
+    R0 = helpers.rot_xyz(0.01, 0.02, -0.03)
+    pose = solvers.Pose(R0, [0.1, 0.2, 0.3])
+    assert not solver.Solve(solvers.Options(), planes, pose)
+    np.testing.assert_array_equal(pose.t, [0.1, 0.2, 0.3])
+    np.testing.assert_array_equal(pose.R, R0)
+    # and the solver object is still usable afterwards
+    good = synth.ndt_planes(n, max(10, n // 40))
+    pose = solvers.Pose()
+    assert solver.Solve(solvers.Options(), good, pose)
