@@ -258,7 +258,45 @@ int nos_pgo_solve(nos_pose_graph* pg, double lambda, int max_iterations, double 
   NOS_HIP_CHECK(hipMemcpyAsync(pg->d_p, pg->d_z, n * sizeof(double), hipMemcpyDeviceToDevice, slot.stream));
   int it = 0;
   double res = b_norm;
-  if (b_norm > 0.0) {
+  if (b_norm > 0.0 && env_int("NOS_PGO_HOST_SCALARS", 0) == 0) {
+    // CG scalars stay on the device (pgo_cg_alpha / beta kernels); the host looks at |r| only every kCheck iterations,
+    // so up to kCheck - 1 iterations more than strictly needed may run (they only improve the step).
+    constexpr int kCheck = 8;
+    const double init[8] = {0.0, 0.0, 0.0, rr, rz, 0.0, 0.0, 0.0};
+    NOS_HIP_CHECK(hipMemcpyAsync(pg->d_scalars, init, sizeof init, hipMemcpyHostToDevice, slot.stream));
+    NOS_HIP_CHECK(hipStreamSynchronize(slot.stream));  // `init` is a stack array
+    const double stop = rel_tolerance * b_norm;
+    while (it < max_iterations) {
+      const int batch = std::min(kCheck, max_iterations - it);
+      for (int k = 0; k < batch; ++k) {
+        rc = pgo_matvec(pg, lambda, pg->d_p, pg->d_ap, nullptr);
+        if (rc != NOS_OK) return rc;
+        {
+          uint32_t blocks = (pg->n_poses + 255) / 256;
+          if (pg->n_free_switches > 0) blocks += (pg->n_edges + 255) / 256;
+          hipLaunchKernelGGL(nos::pgo_sum_partials_kernel, dim3(1), dim3(1024), 0, slot.stream, pg->d_partials, blocks, 1,
+                             pg->d_scalars);
+        }
+        hipLaunchKernelGGL(nos::pgo_cg_alpha_kernel, dim3(1), dim3(1), 0, slot.stream, pg->d_scalars);
+        hipLaunchKernelGGL(nos::pgo_cg_update_dev_kernel, dim3(vblocks), dim3(256), 0, slot.stream, n, pg->d_scalars, pg->d_p,
+                           pg->d_ap, pg->d_x, pg->d_r);
+        hipLaunchKernelGGL(nos::pgo_apply_precond_kernel, dim3(pblocks), dim3(256), 0, slot.stream, pg->d_minv, pg->d_hs, lambda,
+                           pg->n_poses, active_edges, pg->d_r, pg->d_r + N6, pg->d_z, pg->d_z + N6, pg->d_partials);
+        hipLaunchKernelGGL(nos::pgo_sum_partials_kernel, dim3(1), dim3(1024), 0, slot.stream, pg->d_partials, pblocks, 2,
+                           pg->d_scalars);
+        hipLaunchKernelGGL(nos::pgo_cg_beta_kernel, dim3(1), dim3(1), 0, slot.stream, pg->d_scalars);
+        hipLaunchKernelGGL(nos::pgo_cg_direction_dev_kernel, dim3(vblocks), dim3(256), 0, slot.stream, n, pg->d_scalars,
+                           pg->d_z, pg->d_p);
+        NOS_HIP_CHECK(hipGetLastError());
+      }
+      it += batch;
+      double sc[8];
+      rc = pgo_read_scalars(pg, 8, sc);
+      if (rc != NOS_OK) return rc;
+      res = std::sqrt(sc[3]);
+      if (sc[7] != 0.0 || !(res > stop)) break;  // breakdown, or converged (NaN also ends the loop)
+    }
+  } else if (b_norm > 0.0) {
     for (; it < max_iterations; ++it) {
       double pap = 0.0;
       rc = pgo_matvec(pg, lambda, pg->d_p, pg->d_ap, &pap);

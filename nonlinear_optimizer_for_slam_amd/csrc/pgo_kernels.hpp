@@ -521,6 +521,44 @@ __global__ __launch_bounds__(256) void pgo_cg_direction_kernel(size_t n, double 
 
 // sums `count` block partials (`width` interleaved values each) in a fixed order: 1024 lanes stride the
 // rows with four independent accumulators, then a fixed tree over the lanes
+// Device-resident CG scalars (no host round trip inside a PCG iteration).  s[0], s[1] receive the sums of the partials
+// kernels as before; s[3] = |r|^2 of the latest iterate, s[4] = r·z of the current direction, s[5] = alpha, s[6] = beta,
+// s[7] = 1 after a breakdown (p·Ap <= 0 or not finite: the iterate is kept from then on).
+__global__ void pgo_cg_alpha_kernel(double* __restrict__ s) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double pap = s[0];
+  if (s[7] != 0.0 || !(pap > 0.0) || !(pap <= 1.79769313486231570e308)) {
+    s[5] = 0.0;
+    s[7] = 1.0;
+  } else {
+    s[5] = s[4] / pap;
+  }
+}
+__global__ void pgo_cg_beta_kernel(double* __restrict__ s) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double rz_new = s[0];
+  s[3] = s[1];
+  const double rz = s[4];
+  s[6] = (s[7] != 0.0 || !(rz > 0.0)) ? 0.0 : rz_new / rz;
+  if (s[7] == 0.0) s[4] = rz_new;
+}
+__global__ __launch_bounds__(256) void pgo_cg_update_dev_kernel(size_t n, const double* __restrict__ s,
+                                                                const double* __restrict__ p, const double* __restrict__ q,
+                                                                double* __restrict__ x, double* __restrict__ r) {
+  const size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double alpha = s[5];
+  x[i] += alpha * p[i];
+  r[i] -= alpha * q[i];
+}
+__global__ __launch_bounds__(256) void pgo_cg_direction_dev_kernel(size_t n, const double* __restrict__ s,
+                                                                   const double* __restrict__ z, double* __restrict__ p) {
+  const size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= n) return;
+  if (s[7] != 0.0) return;  // after a breakdown the direction is frozen (alpha is 0 anyway)
+  p[i] = z[i] + s[6] * p[i];
+}
+
 __global__ __launch_bounds__(1024) void pgo_sum_partials_kernel(const double* __restrict__ partials, uint32_t count,
                                                                 int width, double* __restrict__ out) {
   __shared__ double lds[1024];
