@@ -976,6 +976,244 @@ __global__ __launch_bounds__(BLOCK) void solve_single_block_kernel(TiledLayout L
   }
 }
 
+// ---------------------------------------------------------------- whole solve in one launch, one chunk per workgroup
+//
+// Between the single-workgroup form above and the sizes where a launch is mostly streaming (a few 10^5 correspondences)
+// an LM iteration through one launch per iteration costs ≈ 12.6 µs, of which the kernel boundary, the dispatch of the
+// next grid and its first loads are more than a third.  For up to kClusterMaxBlocks chunks (one 512-thread workgroup per
+// CU, all resident at once) the whole loop runs in ONE launch: every workgroup keeps its chunk in REGISTERS for all
+// iterations, the per-iteration hand-off is the same ticket scheme as in the grid kernel, the finishing workgroup runs
+// LmAdvance*, writes the new state with write-through (sc1) stores and bumps an epoch word; the other workgroups poll the
+// epoch (one lane, sc1 loads) and read the new pose with sc1 loads.  Every wait is bounded (kClusterTimeoutTicks): a
+// workgroup that waits longer — e.g. because another process holds CUs and the grid is not fully resident — raises
+// `abort` and everybody leaves; the host then re-runs the solve with one launch per iteration.
+constexpr uint32_t kClusterMaxBlocks = 256;
+constexpr unsigned long long kClusterTimeoutTicks = 5000000ull;  // 50 ms of the 100 MHz wall clock per iteration
+
+struct ClusterCtl {
+  unsigned int epoch;  // iterations completed (published by the finishing workgroup)
+  unsigned int abort;  // 1: a wait timed out, the launch gave up
+};
+
+__device__ __forceinline__ double sc1_load(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void sc1_store(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// state <-> device memory through write-through stores / cache-bypassing loads (element-wise: the struct is plain data)
+__device__ __forceinline__ void state_store_sc1(LmDevice* lm, const nos_host::LmState& st) {
+  double* d = reinterpret_cast<double*>(&lm->st);
+  const double* s = reinterpret_cast<const double*>(&st);
+  constexpr int kWords = int(sizeof(nos_host::LmState) / sizeof(double));
+  static_assert(sizeof(nos_host::LmState) % sizeof(double) == 0, "LmState must be a whole number of doubles");
+#pragma unroll
+  for (int k = 0; k < kWords; ++k) sc1_store(d + k, s[k]);
+}
+__device__ __forceinline__ void state_load_sc1(const LmDevice* lm, nos_host::LmState& st) {
+  const double* d = reinterpret_cast<const double*>(&lm->st);
+  double* s = reinterpret_cast<double*>(&st);
+  constexpr int kWords = int(sizeof(nos_host::LmState) / sizeof(double));
+#pragma unroll
+  for (int k = 0; k < kWords; ++k) s[k] = sc1_load(d + k);
+}
+
+template <typename Problem, typename T, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void solve_cluster_kernel(TiledLayout L, typename Problem::Params P,
+                                                             double* __restrict__ partials, unsigned int* counter,
+                                                             LmDevice* lm, ClusterCtl* ctl, unsigned int epoch_base,
+                                                             double* __restrict__ cost_history, int history_capacity,
+                                                             double* entry_host, unsigned long long* seq_host,
+                                                             unsigned long long seq) {
+  constexpr int kF = Problem::kFields;
+  constexpr int kOut = Problem::kOut;
+  constexpr int kCols = 32;
+  constexpr int kSlices = BLOCK / kCols;
+  const T* __restrict__ base = static_cast<const T*>(L.base);
+  __shared__ unsigned int s_last;
+  __shared__ int s_flag;  // 0 go on, 1 loop finished, 2 abort
+  __shared__ double red[kSlices][kCols];
+  __shared__ double s_tot[kOut];
+  __shared__ double s_pose[12];
+  __shared__ double s_state_raw[(sizeof(nos_host::LmState) + 7) / 8];  // the loop state as of the current iteration
+  nos_host::LmState& s_state = *reinterpret_cast<nos_host::LmState*>(s_state_raw);
+
+  // this workgroup's chunk, read once
+  const uint64_t i0 = uint64_t(blockIdx.x) * BLOCK + threadIdx.x;
+  const uint64_t off = (i0 >> L.tile_shift) * L.tile_stride + (i0 & L.tile_mask);
+  T x[kF];
+  {
+    T xt[kF][1];
+#pragma unroll
+    for (int f = 0; f < kF; ++f) load_items<T, 1, false>(base + off + uint64_t(f) * L.field_stride, xt[f]);
+#pragma unroll
+    for (int f = 0; f < kF; ++f) x[f] = xt[f][0];
+  }
+  const bool valid = i0 < L.n;
+  const nos_host::LmSettings settings = lm->settings;  // constant during the launch
+  if (threadIdx.x == 0) {
+    s_state = lm->st;  // written by lm_init_kernel before this launch
+    s_flag = s_state.done != 0 ? 1 : 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) s_pose[k] = s_state.R[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) s_pose[9 + k] = s_state.t[k];
+  }
+  __syncthreads();
+  unsigned int it = epoch_base;  // the epoch word is monotonic across launches (the host passes where it stands)
+  bool wrote_last = false;  // this workgroup finished the most recent iteration
+  int executed = 0;
+  while (s_flag == 0) {
+    // pose of this iteration from LDS → scalar registers
+    {
+      LmDevice* fake = nullptr;
+      (void)fake;
+      if constexpr (kOut == 28) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) P.R[k] = T(uniform_load(&s_pose[k]));
+#pragma unroll
+        for (int k = 0; k < 3; ++k) P.t[k] = T(uniform_load(&s_pose[9 + k]));
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) P.R2[k] = T(uniform_load(&s_pose[k]));
+#pragma unroll
+        for (int k = 0; k < 2; ++k) P.t2[k] = T(uniform_load(&s_pose[9 + k]));
+      }
+    }
+    T acc[kOut];
+#pragma unroll
+    for (int k = 0; k < kOut; ++k) acc[k] = T(0);
+    Problem::item(x, P, valid, acc);
+    double dacc[kOut];
+#pragma unroll
+    for (int k = 0; k < kOut; ++k) dacc[k] = double(acc[k]);
+    block_reduce_store<kOut, BLOCK>(dacc, partials + size_t(blockIdx.x) * kOut, true);  // sc1 row
+    if (threadIdx.x < kWave) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0) {
+      unsigned int last = 0u;
+      const unsigned int group = blockIdx.x & 7u;
+      const unsigned int group_size = (gridDim.x - group + 7u) >> 3;
+      const unsigned int n_groups = gridDim.x < 8u ? gridDim.x : 8u;
+      unsigned int* group_counter = counter + 32u * (1u + group);
+      const unsigned int t1 = __hip_atomic_fetch_add(group_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t1 == group_size - 1u) {
+        __hip_atomic_store(group_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int t2 = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = (t2 == n_groups - 1u) ? 1u : 0u;
+      }
+      s_last = last;
+    }
+    __syncthreads();
+    wrote_last = s_last != 0u;
+    if (wrote_last) {  // block-uniform
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int col = threadIdx.x % kCols;
+      const int slice = threadIdx.x / kCols;
+      constexpr int kUnroll = 16;
+      double sum = 0.0;
+      if (col < kOut) {
+        const double* p = partials + col;
+        for (uint32_t r = slice; r < gridDim.x; r += kUnroll * kSlices) {
+          double v[kUnroll];
+#pragma unroll
+          for (int u = 0; u < kUnroll; ++u) {
+            const uint32_t rr = r + u * kSlices;
+            const double q = sc1_load(p + size_t(rr < gridDim.x ? rr : r) * kOut);
+            v[u] = rr < gridDim.x ? q : 0.0;
+          }
+#pragma unroll
+          for (int u = 0; u < kUnroll; ++u) sum += v[u];
+        }
+      }
+      red[slice][col] = sum;
+      __syncthreads();
+      if (threadIdx.x < kOut) {
+        double tot = 0.0;
+#pragma unroll
+        for (int sl = 0; sl < kSlices; ++sl) tot += red[sl][threadIdx.x];
+        s_tot[threadIdx.x] = tot;
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        nos_host::LmState st = s_state;  // every workgroup fetched the state of this iteration together with the pose
+        double out[kOut];
+#pragma unroll
+        for (int k = 0; k < kOut; ++k) out[k] = s_tot[k];
+        if (cost_history != nullptr && executed < history_capacity)
+          __hip_atomic_store(cost_history + executed, out[kOut - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if constexpr (kOut == 28)
+          nos_host::LmAdvance6(settings, out, &st);
+        else
+          nos_host::LmAdvance3(settings, out, &st);
+        state_store_sc1(lm, st);
+        __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // tickets ready for the next iteration
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // state and counter are out before the epoch
+        __hip_atomic_store(&ctl->epoch, it + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    ++executed;
+    // everybody: wait for the epoch of this iteration, then fetch the new pose / the done flag
+    if (threadIdx.x == 0) {
+      const unsigned long long deadline = wall_clock64() + kClusterTimeoutTicks;
+      int flag = 0;
+      unsigned int polls = 0;
+      while (__hip_atomic_load(&ctl->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != it + 1u) {
+        // the abort word and the clock are looked at every 16th poll only: the common case is one load per poll
+        if ((++polls & 15u) == 0u &&
+            (__hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || wall_clock64() > deadline)) {
+          __hip_atomic_store(&ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          flag = 2;
+          break;
+        }
+      }
+      if (flag == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        nos_host::LmState st;
+        state_load_sc1(lm, st);  // one batch of cache-bypassing loads: pose for everybody, the rest for the next finisher
+        s_state = st;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) s_pose[k] = st.R[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) s_pose[9 + k] = st.t[k];
+        flag = st.done != 0 ? 1 : 0;
+      }
+      s_flag = flag;
+    }
+    __syncthreads();
+    ++it;
+  }
+  // the workgroup that finished the last iteration reports (on abort nobody does: the host sees the missing sequence word)
+  if (s_flag == 1 && (wrote_last || (executed == 0 && blockIdx.x == 0))) {
+    if (threadIdx.x < kOut && entry_host != nullptr && executed > 0)
+      __hip_atomic_store(entry_host + kLogOut + threadIdx.x, s_tot[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0 && entry_host != nullptr) {
+      const nos_host::LmState st = s_state;
+#pragma unroll
+      for (int k = 0; k < 9; ++k)
+        __hip_atomic_store(entry_host + kLogR + k, st.R[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        __hip_atomic_store(entry_host + kLogT + k, st.t[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(entry_host + kLogLambda, st.lambda, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(entry_host + kLogPrevCost, st.previous_cost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(entry_host + kLogCost, st.cost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(entry_host + kLogIteration, double(st.iteration), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(entry_host + kLogDone, double(st.done), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(entry_host + kLogOk, double(st.ok), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(entry_host + kLogExecuted, double(executed), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (threadIdx.x < kWave) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (threadIdx.x == 0 && seq_host != nullptr) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(seq_host, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------- voxel-indexed variant
 //
 // The reference's data model copies the whole NDT into every correspondence (MDM/types.h:23-26), which

@@ -165,6 +165,12 @@ int launch_by_variant(int variant, int blocks_per_cu, int num_cus, const nos::Ti
 
 // Arguments of the single-workgroup whole-solve kernel (small problems, see nos::solve_single_block_kernel).
 struct SingleBlockArgs {
+  // cluster form (one chunk per workgroup, whole loop in one launch) when cluster_blocks > 0
+  int cluster_blocks = 0;
+  double* partials = nullptr;
+  unsigned int* counter = nullptr;
+  nos::ClusterCtl* ctl = nullptr;
+  unsigned int epoch_base = 0;
   nos::LmDevice* lm;
   double* history;  // device address of the pinned cost history (may be null)
   int history_capacity;
@@ -177,6 +183,14 @@ template <typename Problem, typename T>
 int launch_single(const nos::TiledLayout& L, const typename Problem::Params& P, const SingleBlockArgs& a, hipStream_t stream) {
   constexpr int kBlock = 512;
   if (L.n_padded % kBlock != 0) return fail(NOS_ERR_INVALID_ARGUMENT, "n_padded %% 512 != 0");
+  if (a.cluster_blocks > 0) {
+    hipLaunchKernelGGL((nos::solve_cluster_kernel<Problem, T, kBlock>), dim3(a.cluster_blocks), dim3(kBlock), 0, stream, L, P,
+                       a.partials, a.counter, a.lm, a.ctl, a.epoch_base, a.history, a.history_capacity, a.entry, a.seq_host,
+                       a.seq);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(NOS_ERR_HIP, "cluster solve launch failed: %s", hipGetErrorString(e));
+    return NOS_OK;
+  }
   const uint32_t n_chunks = uint32_t((std::max<uint64_t>(L.n, 1) + kBlock - 1) / kBlock);  // pads beyond are never read
   hipLaunchKernelGGL((nos::solve_single_block_kernel<Problem, T, kBlock>), dim3(1), dim3(kBlock), 0, stream, L, P, n_chunks, a.lm,
                      a.history, a.history_capacity, a.entry, a.seq_host, a.seq);
@@ -569,14 +583,18 @@ int lm_solve(nos_dataset* ds, const Request& rq, const nos_lm_options* opt, doub
   hipLaunchKernelGGL(nos::lm_init_kernel, dim3(1), dim3(1), 0, slot.stream, slot.d_lm, init);
   NOS_HIP_CHECK(hipGetLastError());
 
-  const unsigned long long base_seq = slot.seq;
   unsigned long long* seq_dev = reinterpret_cast<unsigned long long*>(slot.h_out_dev + kSeqSlot);
   // Small problems: the whole loop in one workgroup and one launch (see nos::solve_single_block_kernel)
   if (ds->kind != kKindNdtIndexed && !with_comm && ctx->shm_dev == nullptr && opt->max_iterations > 0 &&
       sh.layout.n * size_t(ds->n_fields) <= nos::kSingleBlockMaxElements && env_int("NOS_LM_SINGLE", 1) != 0 &&
       (opt->cost_history == nullptr || opt->max_iterations <= kHistCapacity)) {
-    SingleBlockArgs single{slot.d_lm, opt->cost_history ? slot.h_hist_dev : nullptr, kHistCapacity, slot.h_log_dev, seq_dev,
-                           ++slot.seq};
+    SingleBlockArgs single{};
+    single.lm = slot.d_lm;
+    single.history = opt->cost_history ? slot.h_hist_dev : nullptr;
+    single.history_capacity = kHistCapacity;
+    single.entry = slot.h_log_dev;
+    single.seq_host = seq_dev;
+    single.seq = ++slot.seq;
     int rows = 0;
     int rc = launch_assemble_raw(ds, sh, rq, slot.partials, nos::FusedFinal{}, slot.stream, &rows, &single);
     if (rc != NOS_OK) return rc;
@@ -607,6 +625,84 @@ int lm_solve(nos_dataset* ds, const Request& rq, const nos_lm_options* opt, doub
     }
     return NOS_OK;
   }
+  // Mid-size problems: one chunk per workgroup, every workgroup resident, the whole loop in one launch
+  // (nos::solve_cluster_kernel).  If a wait inside times out (grid not fully resident, e.g. the GPU is shared) the
+  // launch gives up and the code below runs the loop with one launch per iteration instead.
+  const size_t cluster_blocks = (sh.layout.n + 511) / 512;
+  if (ds->kind != kKindNdtIndexed && !with_comm && ctx->shm_dev == nullptr && opt->max_iterations > 0 &&
+      cluster_blocks >= 1 && cluster_blocks <= nos::kClusterMaxBlocks && cluster_blocks <= size_t(slot.num_cus) &&
+      env_int("NOS_LM_CLUSTER", 1) != 0 && (opt->cost_history == nullptr || opt->max_iterations <= kHistCapacity)) {
+    SingleBlockArgs cl{};
+    cl.cluster_blocks = int(cluster_blocks);
+    cl.partials = slot.partials;
+    cl.counter = slot.counter;
+    cl.ctl = slot.d_cluster;
+    cl.epoch_base = slot.cluster_epoch;
+    cl.lm = slot.d_lm;
+    cl.history = opt->cost_history ? slot.h_hist_dev : nullptr;
+    cl.history_capacity = kHistCapacity;
+    cl.entry = slot.h_log_dev;
+    cl.seq_host = seq_dev;
+    cl.seq = ++slot.seq;
+    int rows = 0;
+    int rc = launch_assemble_raw(ds, sh, rq, slot.partials, nos::FusedFinal{}, slot.stream, &rows, &cl);
+    if (rc != NOS_OK) return rc;
+    // spin on the sequence word; a launch that gave up never writes it
+    volatile unsigned long long* seqw = reinterpret_cast<volatile unsigned long long*>(slot.h_out + kSeqSlot);
+    bool finished = false;
+    for (long spins = 0; spins < 4000000; ++spins) {
+      if (*seqw >= cl.seq) {
+        finished = true;
+        break;
+      }
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
+    }
+    if (!finished) {
+      NOS_HIP_CHECK(hipStreamSynchronize(slot.stream));
+      finished = *seqw >= cl.seq;
+    }
+    if (finished) {
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+      const double* e = slot.h_log;
+      for (int k = 0; k < 9; ++k) st.R[k] = e[nos::kLogR + k];
+      for (int k = 0; k < 3; ++k) st.t[k] = e[nos::kLogT + k];
+      st.lambda = e[nos::kLogLambda];
+      st.previous_cost = e[nos::kLogPrevCost];
+      st.cost = e[nos::kLogCost];
+      st.iteration = int(e[nos::kLogIteration]);
+      st.done = int(e[nos::kLogDone]);
+      st.ok = int(e[nos::kLogOk]);
+      const int executed = int(e[nos::kLogExecuted]);
+      slot.cluster_epoch += unsigned(executed);
+      if (opt->cost_history != nullptr)
+        for (int k = 0; k < executed && k < opt->max_iterations; ++k) opt->cost_history[k] = slot.h_hist[k];
+      for (int k = 0; k < nR; ++k) R[k] = st.R[k];
+      for (int k = 0; k < nt; ++k) t[k] = st.t[k];
+      if (report) {
+        report->iterations = st.iteration;
+        report->ok = st.ok;
+        report->launches = 1;
+        report->reserved = 0;
+        report->printed_cost = st.previous_cost;
+        report->last_cost = st.cost;
+        report->final_lambda = st.lambda;
+      }
+      return NOS_OK;
+    }
+    // gave up: put the shared words back in order and fall through to the launch-per-iteration loop from the start
+    NOS_HIP_CHECK(hipMemsetAsync(slot.d_cluster, 0, sizeof(nos::ClusterCtl), slot.stream));
+    NOS_HIP_CHECK(hipMemsetAsync(slot.counter, 0, 2048, slot.stream));
+    slot.cluster_epoch = 0;
+    hipLaunchKernelGGL(nos::lm_init_kernel, dim3(1), dim3(1), 0, slot.stream, slot.d_lm, init);
+    NOS_HIP_CHECK(hipGetLastError());
+    if (init.dof == 6)
+      nos_host::LmInit6(&st, init.R, init.t, opt->max_iterations);
+    else
+      nos_host::LmInit3(&st, init.R, init.t, opt->max_iterations);
+  }
+  const unsigned long long base_seq2 = slot.seq;
   int launched = 0, completed = 0;
   auto launch_one = [&]() -> int {
     double* entry = slot.h_log_dev + size_t(launched % kLogSlots) * nos::kLogEntryDoubles;
@@ -643,7 +739,7 @@ int lm_solve(nos_dataset* ds, const Request& rq, const nos_lm_options* opt, doub
   int rc = NOS_OK;
   while (rc == NOS_OK && launched < std::min(window, opt->max_iterations)) rc = launch_one();
   while (rc == NOS_OK && completed < launched) {
-    rc = wait_for_sequence(slot, base_seq + completed + 1);
+    rc = wait_for_sequence(slot, base_seq2 + completed + 1);
     if (rc == NOS_OK) rc = check_mailbox_error(ctx, slot);
     if (rc != NOS_OK) break;
     if (!st.done) {
@@ -1035,6 +1131,8 @@ int nos_ctx_create(const int* device_ids, int n_devices, nos_ctx** out_ctx) {
     if (e == hipSuccess) e = hipHostMalloc(&s.h_log, log_bytes, hipHostMallocMapped);
     if (e == hipSuccess) memset(s.h_log, 0, log_bytes);
     if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&s.h_log_dev), s.h_log, 0);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s.d_cluster), sizeof(nos::ClusterCtl));
+    if (e == hipSuccess) e = hipMemset(s.d_cluster, 0, sizeof(nos::ClusterCtl));
     if (e == hipSuccess) e = hipHostMalloc(&s.h_hist, sizeof(double) * kHistCapacity, hipHostMallocMapped);
     if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&s.h_hist_dev), s.h_hist, 0);
     if (e == hipSuccess) e = hipMalloc(&s.counter, 2048);  // top ticket + 8 group tickets, 128 bytes apart
@@ -1109,6 +1207,7 @@ int nos_ctx_destroy(nos_ctx* ctx) {
     s.pool.clear();
     if (s.h_log) (void)hipHostFree(s.h_log);
     if (s.h_hist) (void)hipHostFree(s.h_hist);
+    if (s.d_cluster) (void)hipFree(s.d_cluster);
     if (s.ev0) (void)hipEventDestroy(s.ev0);
     if (s.ev1) (void)hipEventDestroy(s.ev1);
     if (s.ev2) (void)hipEventDestroy(s.ev2);
