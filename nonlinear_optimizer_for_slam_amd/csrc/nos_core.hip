@@ -610,6 +610,7 @@ int lm_solve(nos_dataset* ds, const Request& rq, const nos_lm_options* opt, doub
     st.done = int(e[nos::kLogDone]);
     st.ok = int(e[nos::kLogOk]);
     const int executed = int(e[nos::kLogExecuted]);
+    if (slot.prof_on && slot.prof_every == 0) slot.prof_launches += executed;  // bracket profiling counts passes over the data
     if (opt->cost_history != nullptr)
       for (int k = 0; k < executed && k < opt->max_iterations; ++k) opt->cost_history[k] = slot.h_hist[k];
     for (int k = 0; k < nR; ++k) R[k] = st.R[k];
@@ -676,6 +677,7 @@ int lm_solve(nos_dataset* ds, const Request& rq, const nos_lm_options* opt, doub
       st.ok = int(e[nos::kLogOk]);
       const int executed = int(e[nos::kLogExecuted]);
       slot.cluster_epoch += unsigned(executed);
+      if (slot.prof_on && slot.prof_every == 0) slot.prof_launches += executed;  // bracket profiling counts passes over the data
       if (opt->cost_history != nullptr)
         for (int k = 0; k < executed && k < opt->max_iterations; ++k) opt->cost_history[k] = slot.h_hist[k];
       for (int k = 0; k < nR; ++k) R[k] = st.R[k];
