@@ -1159,8 +1159,8 @@ __global__ __launch_bounds__(BLOCK) void solve_cluster_kernel(TiledLayout L, typ
       int flag = 0;
       unsigned int polls = 0;
       while (__hip_atomic_load(&ctl->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != it + 1u) {
-        // the abort word and the clock are looked at every 16th poll only: the common case is one load per poll
-        if ((++polls & 15u) == 0u &&
+        // the abort word and the clock are looked at on the first and then every 16th poll
+        if ((polls++ & 15u) == 0u &&
             (__hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || wall_clock64() > deadline)) {
           __hip_atomic_store(&ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           flag = 2;

@@ -645,6 +645,11 @@ int lm_solve(nos_dataset* ds, const Request& rq, const nos_lm_options* opt, doub
     cl.entry = slot.h_log_dev;
     cl.seq_host = seq_dev;
     cl.seq = ++slot.seq;
+    if (env_int("NOS_TEST_CLUSTER_ABORT", 0) != 0) {  // test hook: the launch finds `abort` already raised and gives up
+      const nos::ClusterCtl raised{slot.cluster_epoch, 1u};
+      NOS_HIP_CHECK(hipMemcpyAsync(slot.d_cluster, &raised, sizeof raised, hipMemcpyHostToDevice, slot.stream));
+      NOS_HIP_CHECK(hipStreamSynchronize(slot.stream));
+    }
     int rows = 0;
     int rc = launch_assemble_raw(ds, sh, rq, slot.partials, nos::FusedFinal{}, slot.stream, &rows, &cl);
     if (rc != NOS_OK) return rc;

@@ -380,3 +380,51 @@ def test_cluster_solve_survives_two_processes_competing_for_the_cus(tmp_path):
         for k in range(len(z["it"])):
             dt, dq = helpers.pose_delta(z["R"][k].reshape(3, 3), z["t"][k], R.reshape(3, 3), t)
             assert dt < 1e-10 and dq < 1e-10, (rank, k, dt, dq, int(z["launches"][k]))
+
+
+def test_cluster_solve_falls_back_when_the_gpu_is_busy(ctx, capsys):
+    """Keep the GPU saturated with a long stream of large torch matmuls and solve at the same time: a cluster launch
+    that cannot get all its workgroups resident within its bounded wait gives up (report: more than one launch) and the
+    solve is redone launch by launch.  Whether or not that happens on a given run, the answer must be the undisturbed one."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("torch cannot see the GPU on this box (environment)")
+    ds = NdtDataset.from_planes(ctx, synth.ndt_planes(125_000, 3000), "f64")   # 245 workgroups
+    R0, t0, r0 = ds.solve6(np.eye(3), np.zeros(3), EXP, max_iterations=40)
+    assert r0["launches"] == 1
+    a = torch.randn(8192, 8192, device="cuda", dtype=torch.float32)
+    side = torch.cuda.Stream()
+    fell_back = 0
+    for _ in range(6):
+        with torch.cuda.stream(side):
+            for _ in range(40):
+                a = torch.tanh(a @ a) * 0.01 + 0.1          # ≈ 100+ ms of work queued on the side stream
+        R, t, r = ds.solve6(np.eye(3), np.zeros(3), EXP, max_iterations=40)
+        fell_back += int(r["launches"] > 1)
+        assert r["ok"] and r["iterations"] == r0["iterations"]
+        dt, dq = helpers.pose_delta(R.reshape(3, 3), t, R0.reshape(3, 3), t0)
+        assert dt < 1e-10 and dq < 1e-10, (dt, dq, r["launches"])
+    torch.cuda.synchronize()
+    with capsys.disabled():
+        print("\n[cluster under load] %d of 6 solves fell back to one launch per iteration" % fell_back)
+    ds.close()
+
+
+def test_cluster_solve_abort_path_redoes_the_solve_launch_by_launch(ctx):
+    """Deterministic exercise of the give-up path (test hook NOS_TEST_CLUSTER_ABORT raises `abort` before the launch):
+    the launch leaves without a result, the host resets the shared words and redoes the solve with one launch per
+    iteration; the next solve uses the one-launch form again."""
+    ds = NdtDataset.from_planes(ctx, synth.ndt_planes(30_000, 900), "f64")
+    good = ds.solve6(np.eye(3), np.zeros(3), EXP, max_iterations=40)
+    assert good[2]["launches"] == 1
+    os.environ["NOS_TEST_CLUSTER_ABORT"] = "1"
+    try:
+        redo = ds.solve6(np.eye(3), np.zeros(3), EXP, max_iterations=40)
+    finally:
+        del os.environ["NOS_TEST_CLUSTER_ABORT"]
+    assert redo[2]["launches"] > 1 and redo[2]["ok"] and redo[2]["iterations"] == good[2]["iterations"]
+    dt, dq = helpers.pose_delta(redo[0].reshape(3, 3), redo[1], good[0].reshape(3, 3), good[1])
+    assert dt < 1e-10 and dq < 1e-10, (dt, dq)
+    again = ds.solve6(np.eye(3), np.zeros(3), EXP, max_iterations=40)
+    assert again[2]["launches"] == 1 and np.array_equal(again[0], good[0]) and np.array_equal(again[1], good[1])
+    ds.close()
