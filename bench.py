@@ -184,34 +184,57 @@ def main():
     #                 no extra kernel, no RCCL call, no host step per iteration; the LM loop is device resident
     #   "rccl-native" ncclAllReduce issued by libnos_hip.so on the launch stream + a one-wave step kernel
     #   "torch.distributed"  all_reduce from a Python callback around nos_ndt6_accumulate_async (host loop)
-    # NOS_BENCH_COMM = mailbox | rccl | torch pins the starting point of that chain.
+    # NOS_BENCH_COMM = auto (default: probe both, keep the faster) | mailbox | rccl | torch.
     comm_mode = "none"
+    comm_probe = {}
     if dist is not None:
         comm_mode = "torch.distributed"
-        want = os.environ.get("NOS_BENCH_COMM", "mailbox")
-        chain = {"mailbox": ["mailbox", "rccl-native"], "rccl": ["rccl-native"], "torch": []}.get(want, [])
-        for candidate in chain:
-            ok = 1.0
+        want = os.environ.get("NOS_BENCH_COMM", "auto")
+        candidates = {"auto": ["mailbox", "rccl-native"], "mailbox": ["mailbox"], "rccl": ["rccl-native"],
+                      "torch": []}.get(want, [])
+
+        def bring_up(candidate):
+            """Collective: init + self-test on every rank, unanimous vote.  → mean µs per all-reduce call, or None."""
+            ok, micros = 1.0, 0.0
             try:
                 with _StdoutToStderr():
                     if candidate == "mailbox":
                         ctx.comm_init_shm_from_torch()
                     else:
                         ctx.comm_init_from_torch()
-                    for _ in range(100):  # many rounds: both parities of the double-buffered mailbox, ranks out of step
+                    for k in range(120):  # many rounds: both parities of the double-buffered mailbox, ranks out of step
+                        if k == 20:
+                            t_probe = time.perf_counter()
                         got = ctx.comm_allreduce([rank + 1.0, 1.0])
                         if abs(got[0] - world * (world + 1) / 2.0) > 1e-12 or abs(got[1] - world) > 1e-12:
                             raise RuntimeError("%s self-test mismatch: %r" % (candidate, got))
+                    micros = 1e6 * (time.perf_counter() - t_probe) / 100.0
             except Exception as exc:  # noqa: BLE001
                 print("[bench] %s unavailable on rank %d: %s" % (candidate, rank, exc), file=sys.stderr)
                 ok = 0.0
-            flag = torch.tensor([ok], device=tdev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if float(flag.item()) > 0.5:
-                comm_mode = candidate
-                break
+            vote = torch.tensor([ok, -micros], dtype=torch.float64, device=tdev)
+            dist.all_reduce(vote, op=dist.ReduceOp.MIN)   # all ranks ok, and the slowest rank's time
+            if float(vote[0].item()) > 0.5:
+                return -float(vote[1].item())
             if ctx.comm_size > 0:
-                ctx.comm_destroy()  # came up here but not everywhere: drop it and try the next candidate
+                ctx.comm_destroy()  # came up here but not everywhere: drop it
+            return None
+
+        # "auto": bring each candidate up, time 100 all-reduce calls of the 28-double payload's kind on THIS machine
+        # (same host-side wrapping for both, so the difference is the exchange itself), keep the faster one — the RCCL form
+        # is charged the ≈ 4 µs of its extra step kernel that the probe does not see.  Identical decision on every rank
+        # (the votes are all-reduced).
+        for candidate in candidates:
+            micros = bring_up(candidate)
+            if micros is not None:
+                comm_probe[candidate] = micros
+                ctx.comm_destroy()
+        if comm_probe:
+            def cost(c):
+                return comm_probe[c] + (4.0 if c == "rccl-native" else 0.0)
+            best = min(comm_probe, key=cost)
+            if bring_up(best) is not None:
+                comm_mode = best
     if not (rank == 0 and world == 1 and not args.no_cpu_baseline):
         del planes
         planes = None
@@ -324,6 +347,7 @@ def main():
             "points_per_gpu": n_local, "total_points": n_total, "voxels": N_VOXELS,
             "loss": "ExponentialLossFunction(1,1)", "parallelism": "corr-shard x%d, all-reduce 28 f64" % world,
             "collective": comm_mode,
+            "collective_probe_us_per_allreduce_call": comm_probe,
             "loop": args.loop if comm_mode != "torch.distributed" else "host",
             "step": ("LM iteration, device resident: assemble kernel + in-launch final reduce%s + 6x6 LDLT / pose update "
                      "/ lambda schedule on the GPU, next launch already queued"
