@@ -317,6 +317,29 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # Second, untimed-for-the-metric pass at N = 1: the same K steps with the loop ON THE HOST (6x6 LDLT, damping and pose
+    # update on the CPU around nos_ndt6_accumulate — the arrangement BASELINE.json's north_star describes literally), so
+    # both placements of the loop are on record from one run.
+    host_loop = None
+    if world == 1 and dist is None and args.loop == "device":
+        ht, hR, hrep = np.zeros(3), np.eye(3).reshape(-1).copy(), np.zeros(5)
+
+        def iterate_host(k):
+            ok = host.nos_host_ndt6_iterate(ds._h, ctypes.byref(loss), ctypes.c_int(k), ht.ctypes.data_as(_lib.c_double_p),
+                                            hR.ctypes.data_as(_lib.c_double_p), hrep.ctypes.data_as(_lib.c_double_p))
+            if not ok or int(hrep[0]) != k:
+                raise RuntimeError("host LM loop failed: ok=%s iterations=%s status=%s" % (ok, hrep[0], hrep[4]))
+
+        iterate_host(max(args.warmup, 1))
+        ctx.synchronize()
+        th = time.perf_counter()
+        iterate_host(args.steps)
+        ctx.synchronize()
+        eh = time.perf_counter() - th
+        host_loop = {"ms_per_step": 1e3 * eh / args.steps, "value": n_local * args.steps / eh, "unit": "corr/s",
+                     "final_translation_error_m": float(np.max(np.abs(ht - synth.true_pose("ndt")[1]))),
+                     "note": "same K steps, LM loop on the host around nos_ndt6_accumulate (north_star's literal arrangement)"}
+
     n_total = n_local * world
     value = n_total * args.steps / elapsed
     bytes_per_launch = ds.stream_bytes  # flat: n * 120 (fp64) / 60 (fp32); indexed: n * (3 * elem + 4)
@@ -389,6 +412,8 @@ def main():
                 break
     except Exception:  # a missing / malformed summary only loses the optional field
         pass
+    if host_loop is not None:
+        result["host_loop"] = host_loop
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         avx, scalar = cpu_baseline(planes, args.cpu_seconds)
         result["cpu_baseline"] = avx
