@@ -299,6 +299,11 @@ int nos_reproj_accumulate_async(nos_dataset* ds, const double R[9], const double
  * the GPU with no host step in between (the host keeps `launches_in_flight` launches queued and reads
  * one pinned log entry per iteration).  Semantics are those of the host loop around nos_*_accumulate
  * (same source for the loop body); only floating-point contraction may differ in the last bits.
+ * Small and mid-size problems run the whole loop in ONE launch: below 1 024 NDT / 3 072 reprojection
+ * correspondences inside a single workgroup; up to 131 072 correspondences with one 512-correspondence chunk per
+ * workgroup held in registers and a bounded epoch hand-off between iterations (if the grid cannot become resident
+ * in time the launch gives up and the solve is redone with one launch per iteration) — report->launches tells
+ * which form ran.
  * With a communicator (nos_ctx_comm_init) each launch is followed by the all-reduce and a one-wave step
  * kernel; every rank ends with identical bits.  Single-device contexts only (NOS_ERR_UNSUPPORTED
  * otherwise: use the host loop).  R / t are in-out. */
