@@ -311,3 +311,35 @@ def test_whole_wrapper_wall_time_on_the_reference_scene(ctx, room, capsys):
     with capsys.disabled():
         print("[wrapper] map build of %d points: %.2f ms" % (len(room["points"]), 1e3 * (time.perf_counter() - t0)))
     gm2.close()
+
+
+@pytest.mark.gpu
+def test_hash_table_and_dense_grid_lookups_give_identical_matches(ctx):
+    """The matcher's two lookup forms (dense column runs; open-addressing hash table for maps whose bounding box is too
+    large) must produce the same records bit for bit — also far away from the map and across its border."""
+    import os
+    from nonlinear_optimizer_for_slam_amd import api
+    rng = np.random.default_rng(23)
+    V, n = 6000, 40_000
+    means = rng.uniform([-30, -12, -2], [30, 12, 4], size=(V, 3))
+    S = rng.normal(size=(V, 3, 3))
+    valid = rng.uniform(size=V) > 0.1
+    pts = rng.uniform([-40, -20, -6], [40, 20, 8], size=(n, 3))      # a good part of the scan lies outside the map
+    pts[:1000] = means[rng.integers(0, V, 1000)] + 0.2 * rng.normal(size=(1000, 3))
+    R = helpers.rot_xyz(0.03, -0.02, 0.2)
+    t = np.array([0.4, -0.3, 0.2])
+    res = {}
+    for dense in ("1", "0"):
+        os.environ["NOS_MATCH_DENSE"] = dense
+        try:
+            m = api.NdtMap(ctx, means, S, valid, 1.0)
+        finally:
+            del os.environ["NOS_MATCH_DENSE"]
+        sc = api.Scan(ctx, pts)
+        ds, nm = m.match(sc, R, t, 2, "f64")
+        res[dense] = (api.download(ds), nm)
+        ds.close()
+        sc.close()
+        m.close()
+    assert res["1"][1] == res["0"][1] and res["1"][1] > 1000
+    assert np.array_equal(res["1"][0], res["0"][0])
