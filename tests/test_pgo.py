@@ -205,3 +205,31 @@ def test_large_graph_generator_and_gpu_loop(ctx):
     c1, g1 = g.linearize()
     assert c1 < 0.02 * c0 and g1 < 1e-3 * g0
     g.close()
+
+
+@pytest.mark.gpu
+def test_pcg_with_device_resident_scalars_equals_host_scalar_pcg(ctx):
+    """The CG scalars (alpha, beta, r.z) live on the device by default and the host looks at |r| every 8th iteration;
+    NOS_PGO_HOST_SCALARS=1 restores the per-iteration readback.  Same arithmetic: at a fixed iteration count (a multiple
+    of 8, tolerance 0) the two must agree to rounding, and both must reach the direct solve."""
+    import os
+    d = op.random_graph(400, 3, seed=9)
+    cpu, gpu = _graph_pair(ctx, d)
+    H, g, _ = cpu.linearize()
+    gpu.linearize()
+    it_dev, res_dev, _ = gpu.solve(1e-4, 64, 0.0)
+    x_dev = gpu.vector("step").copy()
+    os.environ["NOS_PGO_HOST_SCALARS"] = "1"
+    try:
+        it_host, res_host, _ = gpu.solve(1e-4, 64, 0.0)
+    finally:
+        del os.environ["NOS_PGO_HOST_SCALARS"]
+    x_host = gpu.vector("step").copy()
+    assert it_dev == it_host == 64
+    np.testing.assert_allclose(x_dev, x_host, rtol=0, atol=1e-12 * np.max(np.abs(x_host)))
+    assert res_dev == pytest.approx(res_host, rel=1e-6)
+    it, res, _ = gpu.solve(1e-4, 4000, 1e-13)
+    want = cpu.solve_step(H, g, 1e-4)
+    np.testing.assert_allclose(gpu.vector("step"), want, rtol=0, atol=1e-8 * np.max(np.abs(want)))
+    assert it % 8 == 0 or it == 4000 or res <= 1e-13
+    gpu.close()
