@@ -1000,6 +1000,85 @@ int zero_pad_launch(int n_fields, const nos::TiledLayout& L, void* dst, hipStrea
 
 // AoS ingestion: records are streamed in chunks through two device staging buffers so
 // the H2D copy of chunk k+1 overlaps the unpack kernel of chunk k.
+// Host-pack ingestion (first form: AoS → pinned SoA → H2D, double buffered): T host threads gather
+// the n_fields used doubles out of every record into a pinned planar chunk (converted to the dataset's element type),
+// the chunk's planes are copied straight into their final place in the planar layout while the threads pack the next
+// chunk.  Moves 120 (60) instead of 304 bytes per NDT record over PCIe; pays when there are enough host threads, so it
+// is chosen for large inputs only (see create_from_records).  Planar layout only.
+template <typename T>
+void pack_range(const unsigned char* host, size_t stride, const nos::FieldOffsets& fo, int n_fields, size_t first, size_t count,
+                size_t chunk, T* pinned) {
+  for (size_t j = 0; j < count; ++j) {
+    const unsigned char* rec = host + (first + j) * stride;
+    for (int f = 0; f < n_fields; ++f) {
+      double v;
+      memcpy(&v, rec + fo.off[f], sizeof v);
+      pinned[size_t(f) * chunk + j] = T(v);
+    }
+  }
+}
+
+int ingest_host_pack(nos_ctx* ctx, nos_dataset* ds, Shard& sh, const unsigned char* host, size_t stride,
+                     const nos::FieldOffsets& fo, int threads) {
+  DeviceSlot& slot = ctx->slots[sh.slot];
+  const size_t cnt = sh.layout.n;
+  const size_t es = elem_size(ds->dtype);
+  const size_t chunk = size_t(256) << 10;  // records per chunk: 31 MB of fp64 planes
+  const size_t need = chunk * size_t(ds->n_fields) * es;
+  hipError_t e = hipSetDevice(slot.device);
+  if (e == hipSuccess && slot.copy_stream == nullptr) e = hipStreamCreateWithFlags(&slot.copy_stream, hipStreamNonBlocking);
+  for (int b = 0; b < 2 && e == hipSuccess; ++b)
+    if (slot.pack_done[b] == nullptr) e = hipEventCreateWithFlags(&slot.pack_done[b], hipEventDisableTiming);
+  if (e == hipSuccess && slot.pack_bytes < need) {
+    for (int b = 0; b < 2; ++b) {
+      if (slot.pack_pinned[b]) (void)hipHostFree(slot.pack_pinned[b]);
+      slot.pack_pinned[b] = nullptr;
+    }
+    slot.pack_bytes = 0;
+    for (int b = 0; b < 2 && e == hipSuccess; ++b) e = hipHostMalloc(&slot.pack_pinned[b], need, hipHostMallocDefault);
+    if (e == hipSuccess) slot.pack_bytes = need;
+  }
+  bool used[2] = {false, false};
+  int buf = 0;
+  for (size_t first = 0; first < cnt && e == hipSuccess; first += chunk, buf ^= 1) {
+    const size_t count = std::min(chunk, cnt - first);
+    if (used[buf]) e = hipEventSynchronize(slot.pack_done[buf]);  // its previous copies have left the pinned buffer
+    if (e != hipSuccess) break;
+    std::vector<std::thread> pool;
+    const size_t per = (count + size_t(threads) - 1) / size_t(threads);
+    void* const pinned = slot.pack_pinned[buf];
+    const int n_fields = ds->n_fields;
+    const bool f64 = ds->dtype == NOS_F64;
+    for (int w = 0; w < threads; ++w) {
+      const size_t lo = std::min(count, size_t(w) * per), hi = std::min(count, lo + per);
+      if (lo >= hi) break;
+      pool.emplace_back([host, stride, &fo, n_fields, first, lo, hi, pinned, f64]() {
+        constexpr size_t kChunk = size_t(256) << 10;  // = chunk above (plane pitch inside the pinned buffer)
+        if (f64)
+          pack_range<double>(host, stride, fo, n_fields, first + lo, hi - lo, kChunk, static_cast<double*>(pinned) + lo);
+        else
+          pack_range<float>(host, stride, fo, n_fields, first + lo, hi - lo, kChunk, static_cast<float*>(pinned) + lo);
+      });
+    }
+    for (std::thread& th : pool) th.join();
+    for (int f = 0; f < ds->n_fields && e == hipSuccess; ++f) {
+      char* dst = static_cast<char*>(sh.data) + (size_t(f) * sh.layout.field_stride + first) * es;
+      const char* src = static_cast<const char*>(slot.pack_pinned[buf]) + size_t(f) * chunk * es;
+      e = hipMemcpyAsync(dst, src, count * es, hipMemcpyHostToDevice, slot.copy_stream);
+    }
+    if (e == hipSuccess) e = hipEventRecord(slot.pack_done[buf], slot.copy_stream);
+    used[buf] = true;
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(slot.copy_stream);
+  if (e != hipSuccess)
+    return fail(e == hipErrorOutOfMemory ? NOS_ERR_OUT_OF_MEMORY : NOS_ERR_HIP, "host-pack ingestion failed: %s", hipGetErrorString(e));
+  int rc = (ds->dtype == NOS_F64) ? zero_pad_launch<double>(ds->n_fields, sh.layout, sh.data, slot.stream)
+                                  : zero_pad_launch<float>(ds->n_fields, sh.layout, sh.data, slot.stream);
+  if (rc != NOS_OK) return rc;
+  NOS_HIP_CHECK(hipStreamSynchronize(slot.stream));
+  return NOS_OK;
+}
+
 int create_from_records(nos_ctx* ctx, int kind, size_t n, const void* records, size_t stride,
                         const size_t* field_offsets, int dtype, nos_dataset** out) {
   if ((!records && n > 0) || !field_offsets) return fail(NOS_ERR_INVALID_ARGUMENT, "records / offsets is NULL");
@@ -1020,8 +1099,27 @@ int create_from_records(nos_ctx* ctx, int kind, size_t n, const void* records, s
   }
   const size_t chunk_records = std::max<size_t>(1, (size_t(64) << 20) / stride);
   const unsigned char* host = static_cast<const unsigned char*>(records);
+  // Which ingestion: "unpack" ships the raw records and unpacks on the device (no host work, 304 B/record over PCIe);
+  // "pack" gathers on the host with a few threads and ships planes (120 / 60 B/record).  auto = pack for large planar
+  // inputs when the host has threads to spare (NOS_INGEST=pack|unpack forces, NOS_INGEST_THREADS sets the count).
+  const char* mode_env = getenv("NOS_INGEST");
+  const std::string mode = mode_env ? mode_env : "auto";
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  int pack_threads = env_int("NOS_INGEST_THREADS", int(std::min(16u, hw / 2)));
+  const bool planar = ds->tile == 0;
+  const bool use_pack = planar && pack_threads >= 1 &&
+                        (mode == "pack" || (mode == "auto" && n >= (size_t(1) << 20) && pack_threads >= 8));
   size_t begin = 0;
   for (Shard& sh : ds->shards) {
+    if (use_pack) {
+      rc = ingest_host_pack(ctx, ds, sh, host + begin * stride, stride, fo, pack_threads);
+      if (rc != NOS_OK) {
+        nos_dataset_destroy(ds);
+        return rc;
+      }
+      begin += sh.layout.n;
+      continue;
+    }
     DeviceSlot& slot = ctx->slots[sh.slot];
     const size_t cnt = sh.layout.n;
     hipError_t e = hipSetDevice(slot.device);
@@ -1210,6 +1308,10 @@ int nos_ctx_destroy(nos_ctx* ctx) {
       if (s.ing_done[b]) (void)hipEventDestroy(s.ing_done[b]);
     }
     if (s.ing_copied) (void)hipEventDestroy(s.ing_copied);
+    for (int b = 0; b < 2; ++b) {
+      if (s.pack_pinned[b]) (void)hipHostFree(s.pack_pinned[b]);
+      if (s.pack_done[b]) (void)hipEventDestroy(s.pack_done[b]);
+    }
     for (auto& pe : s.pool) (void)hipFree(pe.ptr);
     s.pool.clear();
     if (s.h_log) (void)hipHostFree(s.h_log);

@@ -18,6 +18,7 @@
 #include <memory>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/nos.h"
@@ -92,6 +93,9 @@ struct DeviceSlot {
   hipEvent_t ing_copied = nullptr;
   void* stage[2] = {nullptr, nullptr};
   size_t stage_bytes = 0;
+  void* pack_pinned[2] = {nullptr, nullptr};  // pinned host staging of the host-pack ingestion: [n_fields][chunk] elements
+  size_t pack_bytes = 0;
+  hipEvent_t pack_done[2] = {nullptr, nullptr};
   // Device-buffer pool for dataset storage: nos_dataset_destroy parks the buffer here, the next dataset of a similar
   // size takes it over (the reference's outer loop re-Solves up to 10 times with correspondences of similar count).
   struct PoolEntry {

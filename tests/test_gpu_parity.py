@@ -506,3 +506,35 @@ def test_repeated_cold_solves_do_not_leak_device_memory():
     torch.cuda.synchronize()
     free_after, _ = torch.cuda.mem_get_info()
     assert free_before - free_after < (256 << 20), (free_before, free_after)
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_host_pack_ingestion_equals_device_unpack(ctx, dtype):
+    """Both ingestion forms of the 304-byte records (host threads pack pinned planes | raw records unpacked on the
+    device) must build the same dataset bit for bit, chunk borders and tails included (600 001 records = 3 pack chunks)."""
+    import os
+    n = 600_001
+    planes = synth.ndt_planes(n, 9000)
+    rec = np.zeros((n, 38))
+    rec[:, 0:3] = planes[0:3].T
+    rec[:, 16:19] = planes[3:6].T
+    for i in range(3):
+        for j in range(3):
+            rec[:, 28 + 3 * j + i] = planes[6 + 3 * i + j]
+    offs = [0, 8, 16, 128, 136, 144] + [224 + 8 * (3 * j + i) for i in range(3) for j in range(3)]
+    got = {}
+    for mode in ("unpack", "pack"):
+        os.environ["NOS_INGEST"] = mode
+        os.environ["NOS_INGEST_THREADS"] = "5"
+        try:
+            ds = NdtDataset.from_records(ctx, rec, 304, offs, dtype)
+        finally:
+            del os.environ["NOS_INGEST"]
+            del os.environ["NOS_INGEST_THREADS"]
+        from nonlinear_optimizer_for_slam_amd import api
+        got[mode] = (api.download(ds), ds.accumulate6(R_TEST, T_TEST, ("exponential", 1.0, 1.0)))
+        ds.close()
+    assert np.array_equal(got["pack"][0], got["unpack"][0])
+    assert np.array_equal(got["pack"][1], got["unpack"][1])
+    if dtype == "f64":
+        assert np.array_equal(got["pack"][0], planes)
