@@ -1038,30 +1038,44 @@ int ingest_host_pack(nos_ctx* ctx, nos_dataset* ds, Shard& sh, const unsigned ch
     for (int b = 0; b < 2 && e == hipSuccess; ++b) e = hipHostMalloc(&slot.pack_pinned[b], need, hipHostMallocDefault);
     if (e == hipSuccess) slot.pack_bytes = need;
   }
+  // Worker threads live for the whole call; per chunk they are released by `go` (chunk number) and report through
+  // `arrived`.  The calling thread waits for the pinned buffer to be free, releases the workers, waits for them, enqueues
+  // the chunk's plane copies and moves on while those copies run.
+  const size_t n_chunks = (cnt + chunk - 1) / chunk;
+  std::atomic<long> go{-1};
+  std::atomic<int> arrived{0};
+  void* const pinned2[2] = {slot.pack_pinned[0], slot.pack_pinned[1]};
+  const int n_fields = ds->n_fields;
+  const bool f64 = ds->dtype == NOS_F64;
+  std::vector<std::thread> pool;
+  const int n_workers = (e == hipSuccess && n_chunks > 0) ? threads : 0;
+  for (int w = 0; w < n_workers; ++w) {
+    pool.emplace_back([&, w]() {
+      for (size_t c = 0; c < n_chunks; ++c) {
+        while (go.load(std::memory_order_acquire) < long(c)) std::this_thread::yield();
+        if (go.load(std::memory_order_acquire) == LONG_MAX) return;  // the caller gave up
+        const size_t first = c * chunk, count = std::min(chunk, cnt - first);
+        const size_t per = (count + size_t(n_workers) - 1) / size_t(n_workers);
+        const size_t lo = std::min(count, size_t(w) * per), hi = std::min(count, lo + per);
+        if (lo < hi) {
+          if (f64)
+            pack_range<double>(host, stride, fo, n_fields, first + lo, hi - lo, chunk, static_cast<double*>(pinned2[c & 1]) + lo);
+          else
+            pack_range<float>(host, stride, fo, n_fields, first + lo, hi - lo, chunk, static_cast<float*>(pinned2[c & 1]) + lo);
+        }
+        arrived.fetch_add(1, std::memory_order_release);
+      }
+    });
+  }
   bool used[2] = {false, false};
-  int buf = 0;
-  for (size_t first = 0; first < cnt && e == hipSuccess; first += chunk, buf ^= 1) {
-    const size_t count = std::min(chunk, cnt - first);
+  for (size_t c = 0; c < n_chunks && e == hipSuccess; ++c) {
+    const int buf = int(c & 1);
+    const size_t first = c * chunk, count = std::min(chunk, cnt - first);
     if (used[buf]) e = hipEventSynchronize(slot.pack_done[buf]);  // its previous copies have left the pinned buffer
     if (e != hipSuccess) break;
-    std::vector<std::thread> pool;
-    const size_t per = (count + size_t(threads) - 1) / size_t(threads);
-    void* const pinned = slot.pack_pinned[buf];
-    const int n_fields = ds->n_fields;
-    const bool f64 = ds->dtype == NOS_F64;
-    for (int w = 0; w < threads; ++w) {
-      const size_t lo = std::min(count, size_t(w) * per), hi = std::min(count, lo + per);
-      if (lo >= hi) break;
-      pool.emplace_back([host, stride, &fo, n_fields, first, lo, hi, pinned, f64]() {
-        constexpr size_t kChunk = size_t(256) << 10;  // = chunk above (plane pitch inside the pinned buffer)
-        if (f64)
-          pack_range<double>(host, stride, fo, n_fields, first + lo, hi - lo, kChunk, static_cast<double*>(pinned) + lo);
-        else
-          pack_range<float>(host, stride, fo, n_fields, first + lo, hi - lo, kChunk, static_cast<float*>(pinned) + lo);
-      });
-    }
-    for (std::thread& th : pool) th.join();
-    for (int f = 0; f < ds->n_fields && e == hipSuccess; ++f) {
+    go.store(long(c), std::memory_order_release);
+    while (arrived.load(std::memory_order_acquire) < int(c + 1) * n_workers) std::this_thread::yield();
+    for (int f = 0; f < n_fields && e == hipSuccess; ++f) {
       char* dst = static_cast<char*>(sh.data) + (size_t(f) * sh.layout.field_stride + first) * es;
       const char* src = static_cast<const char*>(slot.pack_pinned[buf]) + size_t(f) * chunk * es;
       e = hipMemcpyAsync(dst, src, count * es, hipMemcpyHostToDevice, slot.copy_stream);
@@ -1069,6 +1083,8 @@ int ingest_host_pack(nos_ctx* ctx, nos_dataset* ds, Shard& sh, const unsigned ch
     if (e == hipSuccess) e = hipEventRecord(slot.pack_done[buf], slot.copy_stream);
     used[buf] = true;
   }
+  go.store(LONG_MAX, std::memory_order_release);  // releases workers still waiting (error path); no-op otherwise
+  for (std::thread& th : pool) th.join();
   if (e == hipSuccess) e = hipStreamSynchronize(slot.copy_stream);
   if (e != hipSuccess)
     return fail(e == hipErrorOutOfMemory ? NOS_ERR_OUT_OF_MEMORY : NOS_ERR_HIP, "host-pack ingestion failed: %s", hipGetErrorString(e));
@@ -1108,7 +1124,7 @@ int create_from_records(nos_ctx* ctx, int kind, size_t n, const void* records, s
   int pack_threads = env_int("NOS_INGEST_THREADS", int(std::min(16u, hw / 2)));
   const bool planar = ds->tile == 0;
   const bool use_pack = planar && pack_threads >= 1 &&
-                        (mode == "pack" || (mode == "auto" && n >= (size_t(1) << 20) && pack_threads >= 8));
+                        (mode == "pack" || (mode == "auto" && n >= size_t(800000) && pack_threads >= 8));
   size_t begin = 0;
   for (Shard& sh : ds->shards) {
     if (use_pack) {
