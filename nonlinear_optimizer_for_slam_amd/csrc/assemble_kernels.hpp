@@ -215,6 +215,64 @@ struct Ndt6Problem {
     // zero-padded records have S = 0 → r = 0, J = 0, rho(0) = 0: no mask needed
     rank_update6<T, 3>(J, r, w, rho, acc);
   }
+
+  // Voxel-indexed form: the voxel table holds A = SᵀS (a00 a01 a02 a11 a12 a22) instead of S.  With J = [S | S M]:
+  //   s = rᵀr = eᵀAe,  g = w [A e ; Mᵀ A e],  H = w [A, A M ; · , Mᵀ A M]
+  // — ≈ 144 instead of ≈ 190 operations per correspondence, 9 instead of 12 values per voxel record.
+  __device__ static __forceinline__ void item_A(const T (&p)[3], const T (&mu)[3], const T (&A)[6], const Params& P,
+                                                T (&acc)[28]) {
+    T e[3], Ae[3], M[3][3], B[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      e[i] = fma(P.R[3 * i], p[0], fma(P.R[3 * i + 1], p[1], fma(P.R[3 * i + 2], p[2], P.t[i]))) - mu[i];
+    const T a00 = A[0], a01 = A[1], a02 = A[2], a11 = A[3], a12 = A[4], a22 = A[5];
+    Ae[0] = fma(a00, e[0], fma(a01, e[1], a02 * e[2]));
+    Ae[1] = fma(a01, e[0], fma(a11, e[1], a12 * e[2]));
+    Ae[2] = fma(a02, e[0], fma(a12, e[1], a22 * e[2]));
+    const T s = fma(e[0], Ae[0], fma(e[1], Ae[1], e[2] * Ae[2]));
+    T rho, w;
+    loss_eval<T, LOSS>(s, P.la, P.lb, P.lc, rho, w);
+    minus_R_hat<T>(P.R, p[0], p[1], p[2], M);
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      B[0][b] = fma(a00, M[0][b], fma(a01, M[1][b], a02 * M[2][b]));
+      B[1][b] = fma(a01, M[0][b], fma(a11, M[1][b], a12 * M[2][b]));
+      B[2][b] = fma(a02, M[0][b], fma(a12, M[1][b], a22 * M[2][b]));
+    }
+    // upper triangle, row-major: rows 0-2 = [A | B], rows 3-5 = MᵀB
+    acc[0] = fma(w, a00, acc[0]);
+    acc[1] = fma(w, a01, acc[1]);
+    acc[2] = fma(w, a02, acc[2]);
+    acc[3] = fma(w, B[0][0], acc[3]);
+    acc[4] = fma(w, B[0][1], acc[4]);
+    acc[5] = fma(w, B[0][2], acc[5]);
+    acc[6] = fma(w, a11, acc[6]);
+    acc[7] = fma(w, a12, acc[7]);
+    acc[8] = fma(w, B[1][0], acc[8]);
+    acc[9] = fma(w, B[1][1], acc[9]);
+    acc[10] = fma(w, B[1][2], acc[10]);
+    acc[11] = fma(w, a22, acc[11]);
+    acc[12] = fma(w, B[2][0], acc[12]);
+    acc[13] = fma(w, B[2][1], acc[13]);
+    acc[14] = fma(w, B[2][2], acc[14]);
+    int k = 15;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = a; b < 3; ++b) {
+        const T c = fma(M[0][a], B[0][b], fma(M[1][a], B[1][b], M[2][a] * B[2][b]));
+        acc[k] = fma(w, c, acc[k]);
+        ++k;
+      }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) acc[21 + i] = fma(w, Ae[i], acc[21 + i]);
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const T gw = fma(M[0][b], Ae[0], fma(M[1][b], Ae[1], M[2][b] * Ae[2]));
+      acc[24 + b] = fma(w, gw, acc[24 + b]);
+    }
+    acc[27] += rho;
+  }
 };
 
 template <typename T, int LOSS>
@@ -257,6 +315,38 @@ struct Ndt3Problem {
 #pragma unroll
     for (int c = 0; c < 3; ++c)
       acc[6 + c] = fma(wJ[0][c], r[0], fma(wJ[1][c], r[1], fma(wJ[2][c], r[2], acc[6 + c])));
+    acc[9] += rho;
+  }
+
+  // Voxel-indexed form with A = SᵀS: J = [S(:,0) S(:,1) S(:,0:2)·d] ⇒ JᵀJ = [[a00, a01, q0], [·, a11, q1], [·, ·, dᵀq]]
+  // with q = A(0:2,0:2)·d, and Jᵀr = [Ae₀, Ae₁, d·(Ae)(0:2)].
+  __device__ static __forceinline__ void item_A(const T (&p)[3], const T (&mu)[3], const T (&A)[6], const Params& P,
+                                                T (&acc)[10]) {
+    const T ux = p[0], uy = p[1];
+    T e[3];
+    e[0] = fma(P.R2[0], ux, fma(P.R2[1], uy, P.t2[0])) - mu[0];
+    e[1] = fma(P.R2[2], ux, fma(P.R2[3], uy, P.t2[1])) - mu[1];
+    e[2] = p[2] - mu[2];
+    const T d0 = fma(P.R2[1], ux, -(P.R2[0] * uy));
+    const T d1 = fma(P.R2[3], ux, -(P.R2[2] * uy));
+    const T a00 = A[0], a01 = A[1], a02 = A[2], a11 = A[3], a12 = A[4], a22 = A[5];
+    const T Ae0 = fma(a00, e[0], fma(a01, e[1], a02 * e[2]));
+    const T Ae1 = fma(a01, e[0], fma(a11, e[1], a12 * e[2]));
+    const T Ae2 = fma(a02, e[0], fma(a12, e[1], a22 * e[2]));
+    const T s = fma(e[0], Ae0, fma(e[1], Ae1, e[2] * Ae2));
+    T rho, w;
+    loss_eval<T, LOSS>(s, P.la, P.lb, P.lc, rho, w);
+    const T q0 = fma(a00, d0, a01 * d1);
+    const T q1 = fma(a01, d0, a11 * d1);
+    acc[0] = fma(w, a00, acc[0]);
+    acc[1] = fma(w, a01, acc[1]);
+    acc[2] = fma(w, q0, acc[2]);
+    acc[3] = fma(w, a11, acc[3]);
+    acc[4] = fma(w, q1, acc[4]);
+    acc[5] = fma(w, fma(d0, q0, d1 * q1), acc[5]);
+    acc[6] = fma(w, Ae0, acc[6]);
+    acc[7] = fma(w, Ae1, acc[7]);
+    acc[8] = fma(w, fma(d0, Ae0, d1 * Ae1), acc[8]);
     acc[9] += rho;
   }
 };
@@ -1219,7 +1309,7 @@ __global__ __launch_bounds__(BLOCK) void solve_cluster_kernel(TiledLayout L, typ
 // The reference's data model copies the whole NDT into every correspondence (MDM/types.h:23-26), which
 // is what the flat 120-byte layout above streams.  When many points share a voxel (10 M points over
 // 200 k voxels = 50 per voxel) the same sums can be formed from  point (3 values) + voxel id(s)  and a
-// table of voxel records {mean(3), sqrt-information(9), pad}: 24 B + 4 B·K per point instead of
+// table of voxel records {mean(3), A = SᵀS (6), pad}: 24 B + 4 B·K per point instead of
 // 120 B·K, with the table (≈ 25 MB at 200 k voxels) served from L2 / Infinity Cache.  Points are
 // stored sorted by voxel id (done once at dataset creation), so the lanes of a wave hit a handful
 // of table records that stay in L1.  The kernel is then fp64-ALU bound, not HBM bound; it is reported
@@ -1227,7 +1317,7 @@ __global__ __launch_bounds__(BLOCK) void solve_cluster_kernel(TiledLayout L, typ
 struct IndexedLayout {
   const void* points;      // 3 planes of n_padded (element type T)
   const int32_t* index;    // K planes of n_padded voxel ids, -1 = no correspondence in that slot
-  const void* table;       // [n_voxels][16] of T: mean(3) sqrt_information(9, row-major) pad(4)
+  const void* table;       // [n_voxels][16] of T: mean(3), A = SᵀS upper triangle (6), pad(7)
   uint64_t n_padded;       // multiple of the kernel chunk; pads carry index -1
 };
 
@@ -1238,7 +1328,7 @@ __device__ __forceinline__ void load_voxel_record(const T* table, int32_t v, T (
     using V2 = double __attribute__((ext_vector_type(2)));
     const V2* q = reinterpret_cast<const V2*>(p);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
+    for (int k = 0; k < 5; ++k) {  // mean (3) + A = SᵀS (6) = 9 values: five 16-byte loads
       const V2 t = q[k];
       rec[2 * k] = t[0];
       rec[2 * k + 1] = t[1];
@@ -1304,13 +1394,9 @@ __global__ __launch_bounds__(BLOCK, MINW) void assemble_indexed_kernel(IndexedLa
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       if (vid[k] >= 0) {
-        T x[15];
-        x[0] = p[0];
-        x[1] = p[1];
-        x[2] = p[2];
-#pragma unroll
-        for (int m = 0; m < 12; ++m) x[3 + m] = rec[k][m];
-        Problem::item(x, P, true, acc);
+        const T mu[3] = {rec[k][0], rec[k][1], rec[k][2]};
+        const T A[6] = {rec[k][3], rec[k][4], rec[k][5], rec[k][6], rec[k][7], rec[k][8]};
+        Problem::item_A(p, mu, A, P, acc);
       }
     }
   };
@@ -1375,7 +1461,7 @@ __global__ __launch_bounds__(256) void gather_plane_kernel(const SRC* __restrict
   dst[j] = j < n ? DST(src[perm ? perm[j] : j]) : pad_value;
 }
 
-// voxel table: [V][3] means + [V][9] sqrt-informations (double) → [V][16] records of T
+// voxel table: [V][3] means + [V][9] sqrt-informations (double) → [V][16] records of T = {mean, SᵀS upper triangle}
 template <typename T>
 __global__ __launch_bounds__(256) void build_voxel_table_kernel(const double* __restrict__ means,
                                                                 const double* __restrict__ sqrt_infos, uint64_t n_voxels,
@@ -1385,10 +1471,14 @@ __global__ __launch_bounds__(256) void build_voxel_table_kernel(const double* __
   const int k = int(t & 15);
   if (v >= n_voxels) return;
   T val = T(0);
-  if (k < 3)
+  if (k < 3) {
     val = T(means[3 * v + k]);
-  else if (k < 12)
-    val = T(sqrt_infos[9 * v + (k - 3)]);
+  } else if (k < 9) {  // A = SᵀS, upper triangle row-major: (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
+    const int ii[6] = {0, 0, 0, 1, 1, 2}, jj[6] = {0, 1, 2, 1, 2, 2};
+    const int i = ii[k - 3], j = jj[k - 3];
+    const double* S = sqrt_infos + 9 * v;
+    val = T(S[i] * S[j] + S[3 + i] * S[3 + j] + S[6 + i] * S[6 + j]);
+  }
   table[t] = val;
 }
 
