@@ -1405,28 +1405,6 @@ __global__ __launch_bounds__(BLOCK, MINW) void assemble_indexed_kernel(IndexedLa
   load_point(c, pt0, id0);
   load_point(c + g, pt1, id1);
   load_records(id0, rc0);
-  if constexpr (K >= 2) {
-    // two records per point: three record buffers do not fit the register file (fp64 spills, fp32 loses occupancy);
-    // two buffers rotated by copy, scheduling left to the compiler — measured faster for K = 2 (A/B on one box:
-    // fp64 0.143 vs 0.162 ms, fp32 0.064 vs 0.067 ms per 5 M points)
-    for (; c < n_chunks; c += g) {
-      load_point(c + 2 * g, pt2, id2);
-      load_records(id1, rc1);
-      evaluate(pt0, id0, rc0);
-#pragma unroll
-      for (int m = 0; m < 3; ++m) {
-        pt0[m] = pt1[m];
-        pt1[m] = pt2[m];
-      }
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        id0[k] = id1[k];
-        id1[k] = id2[k];
-#pragma unroll
-        for (int m = 0; m < 12; ++m) rc0[k][m] = rc1[k][m];
-      }
-    }
-  } else
   for (; c < n_chunks; c += 3 * g) {
     load_point(c + 2 * g, pt2, id2);
     load_records(id1, rc1);
