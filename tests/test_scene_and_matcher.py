@@ -343,3 +343,23 @@ def test_hash_table_and_dense_grid_lookups_give_identical_matches(ctx):
         m.close()
     assert res["1"][1] == res["0"][1] and res["1"][1] > 1000
     assert np.array_equal(res["1"][0], res["0"][0])
+
+
+@pytest.mark.gpu
+def test_scan_to_map_through_the_indexed_layout_equals_the_flat_pipeline(ctx, room):
+    """Matcher → voxel ids → voxel-indexed solve gives the same registration as matcher → 120-byte records → flat solve
+    (same matches, same sums up to rounding), also with a cell-sorted scan."""
+    from nonlinear_optimizer_for_slam_amd import api, pipeline
+    gm, _ = api.NdtMap.build(ctx, room["points"], 1.0, 1.0, proper_sqrt_information=True)
+    flat_scan = api.Scan(ctx, room["local"])
+    pose_f, rounds_f, outer_f = pipeline.scan_to_map(ctx, gm, flat_scan, loss=LOSS)
+    for sort_cell in (None, 1.0):
+        sc = api.Scan(ctx, room["local"], sort_cell=sort_cell)
+        pose_i, rounds_i, outer_i = pipeline.scan_to_map(ctx, gm, sc, loss=LOSS, indexed=True)
+        assert outer_i == outer_f and [r["matches"] for r in rounds_i] == [r["matches"] for r in rounds_f]
+        assert [r["iterations"] for r in rounds_i] == [r["iterations"] for r in rounds_f]
+        dt, dq = helpers.pose_delta(pose_i.R, pose_i.t, pose_f.R, pose_f.t)
+        assert dt < 1e-9 and dq < 1e-9, (dt, dq)
+        sc.close()
+    flat_scan.close()
+    gm.close()
