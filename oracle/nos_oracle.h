@@ -10,12 +10,15 @@
  *   - reprojection path: PINNED end-to-end by the reference's captured run
  *     results/reproj_amd64.txt:5,8,10 ("COST: 2.33228e-11, iter: 6", final pose equal to
  *     the true pose to the printed digits) — tests/test_oracle_golden.py.
- *   - 6-DoF / 3-DoF NDT paths: the reference cannot be compiled here (Eigen, Ceres, FLANN,
- *     simd_helper absent), its tests assert nothing and its captured NDT runs depend on
- *     Eigen's eigenvector sign convention, so per-iteration g/H/cost are pinned only by
- *     (i) an independent numpy restatement, (ii) central finite differences of the cost,
- *     (iii) the sanity band of results/maha_amd64_simple.txt.  Parity for the last digits
- *     of Eigen-dependent arithmetic is UNPINNED.
+ *   - 6-DoF / 3-DoF NDT paths: PINNED end-to-end by the reference's captured runs
+ *     results/maha_amd64_simple.txt:10-13,24, results/maha_3_vs_6_amd64.txt:7-10,19-23,33,35 and
+ *     results/maha_amd64.txt:4-7,55 — 17 `COST: ..., iter: ...` lines, 4 outer_iter counts and 4 final
+ *     poses, every printed digit (tests/test_reference_ndt_runs.py).  That needed the harness's map
+ *     bit for bit: oracle/scene_oracle.c restates UpdateNdtMap's accumulation and Eigen's
+ *     SelfAdjointEigenSolver<Matrix3d> (incl. which multiply-adds the reference binary fuses), and the
+ *     floor(N/4)*4 truncation of the captured revision is applied by the caller
+ *     (oracle_scene.compact_correspondences).  The reference itself cannot be compiled here (Eigen,
+ *     Ceres, FLANN, simd_helper absent), so there is no oracle/_ref.
  *
  * Plane order and output order are those of include/nos.h.
  */

@@ -180,3 +180,158 @@ def match_point_cloud(means, sqrt_infos, valid, local_points, R, t, radius_sq=1.
         planes[3:6, cols] = means[idx[m, k]].T
         planes[6:15, cols] = S[idx[m, k]].T
     return planes, int((idx >= 0).sum()), idx
+
+
+# ----------------------------------------------------------------------------------------------
+# Bit-level restatement (oracle/scene_oracle.c): the accumulation of UpdateNdtMap and Eigen's
+# SelfAdjointEigenSolver<Matrix3d>, which together decide the captured COST lines.
+
+import ctypes as _ct
+import os as _os
+
+_scene_lib = None
+
+# multiply-add sites of scene_oracle.c (bits of fma_mask)
+SITE_TRIDIAG, SITE_SQRT1P, SITE_QR, SITE_Q, SITE_MOMENT_SHIFT, SITE_COV_SHIFT = 4, 8, 16, 32, 8, 17
+
+# The setting that reproduces the reference's captured runs (found by tests/golden/make_ndt_scene_golden.py).
+REFERENCE_EIGEN_VERSION = 34
+# solver sites all contracted; moment += p p^T contracted where Eigen's packet-of-two evaluation through the
+# temporary keeps the product in a register (column-major linear elements 0, 1, 6, 7, 8 = row-major 0, 3, 2, 5, 8);
+# covariance (lazy outer product, no temporary) contracted everywhere.
+REFERENCE_FMA_MASK = (4 | 8 | 16 | 32) | ((1 | 4 | 8 | 32 | 256) << 8) | (0x1ff << 17)
+
+
+def scene_lib():
+    global _scene_lib
+    if _scene_lib is None:
+        from oracle import loader
+        loader.build()
+        path = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "build", "libnos_scene_oracle.so")
+        if not _os.path.exists(path):
+            loader.build(force=True)
+        lib = _ct.CDLL(path)
+        lib.scene_generate_global_points.restype = _ct.c_size_t
+        lib.scene_build_ndt_map.restype = _ct.c_long
+        lib.scene_eigen_selfadjoint3.restype = _ct.c_int
+        _scene_lib = lib
+    return _scene_lib
+
+
+def _p(a, t=_ct.c_double):
+    return a.ctypes.data_as(_ct.POINTER(t))
+
+
+def generate_global_points_c():
+    lib = scene_lib()
+    n = lib.scene_generate_global_points(None, _ct.c_size_t(0))
+    out = np.zeros((n, 3))
+    lib.scene_generate_global_points(_p(out), _ct.c_size_t(n))
+    return out
+
+
+def eigen_selfadjoint3(A, version=None, fma_mask=None):
+    """Eigen::SelfAdjointEigenSolver<Matrix3d>(A) → (eigenvalues ascending [3], eigenvectors as columns [3,3])."""
+    version = REFERENCE_EIGEN_VERSION if version is None else version
+    fma_mask = REFERENCE_FMA_MASK if fma_mask is None else fma_mask
+    A = np.ascontiguousarray(A, dtype=np.float64).reshape(9)
+    w = np.zeros(3)
+    U = np.zeros(9)
+    rc = scene_lib().scene_eigen_selfadjoint3(_p(A), _ct.c_int(version), _ct.c_int(fma_mask), _p(w), _p(U))
+    if rc != 0:
+        raise RuntimeError("NoConvergence")
+    return w, U.reshape(3, 3).T.copy()  # column-major → V[i, k]
+
+
+def build_ndt_map_eigen(points, voxel_resolution=1.0, version=None, fma_mask=None, max_voxels=4096):
+    """UpdateNdtMap with Eigen's solver restated bit for bit; same dict as build_ndt_map (first-seen order)."""
+    version = REFERENCE_EIGEN_VERSION if version is None else version
+    fma_mask = REFERENCE_FMA_MASK if fma_mask is None else fma_mask
+    pts = np.ascontiguousarray(points, dtype=np.float64)
+    keys = np.zeros(max_voxels, dtype=np.uint64)
+    counts = np.zeros(max_voxels, dtype=np.int32)
+    means = np.zeros((max_voxels, 3))
+    S = np.zeros((max_voxels, 3, 3))
+    valid = np.zeros(max_voxels, dtype=np.int32)
+    evals = np.zeros((max_voxels, 3))
+    evecs = np.zeros((max_voxels, 3, 3))
+    V = scene_lib().scene_build_ndt_map(
+        _p(pts), _ct.c_size_t(pts.shape[0]), _ct.c_double(voxel_resolution), _ct.c_int(version), _ct.c_int(fma_mask),
+        _ct.c_size_t(max_voxels), _p(keys, _ct.c_uint64), _p(counts, _ct.c_int), _p(means), _p(S), _p(valid, _ct.c_int),
+        _p(evals), _p(evecs))
+    if V < 0:
+        raise RuntimeError("max_voxels too small")
+    return {"means": means[:V].copy(), "sqrt_infos": S[:V].copy(), "valid": valid[:V].astype(bool), "keys": keys[:V].copy(),
+            "count": counts[:V].copy(), "eigvals": evals[:V].copy(), "eigvecs": evecs[:V].copy()}
+
+
+# ----------------------------------------------------------------------------------------------
+# The reference's captured NDT runs (results/*.txt) as reproducible scenes.
+
+# name → (filter voxel size, true translation, true yaw, dof, file:lines of the captured run)
+CAPTURED_RUNS = {
+    # MDM/tests/simple_optimization_test.cc:72-92 → results/maha_amd64_simple.txt:9-14,24
+    "simple_6dof": (0.1, (-0.2, 0.123, 0.3), 0.1, 6),
+    # MDM/tests/3dof_6dof_comparison_test.cc:64-88 → results/maha_3_vs_6_amd64.txt:6-11,33
+    "planar_3dof": (0.1, (-0.15, 0.05, 0.0), 0.2, 3),
+    # same scene, 6-DoF class → results/maha_3_vs_6_amd64.txt:18-24,35
+    "planar_6dof": (0.1, (-0.15, 0.05, 0.0), 0.2, 6),
+    # MDM/tests/simd_implementation_comparison_test.cc:71-91 → results/maha_amd64.txt:3-8,54-55
+    "dense_6dof": (0.05, (-0.321, 0.123, 0.013), 0.123, 6),
+}
+
+
+def captured_run_scan(points, name):
+    """FilterPoints + WarpPoints(true_pose^-1) of the named captured run → (local points [n,3], R_true, t_true)."""
+    res, tt, yaw, _ = CAPTURED_RUNS[name]
+    f = filter_points(points, res)
+    c, s = np.cos(yaw), np.sin(yaw)
+    Rt = np.array([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]])
+    tt = np.array(tt)
+    return (Rt.T @ (f - tt).T).T, Rt, tt
+
+
+def compact_correspondences(planes, idx, stride=1):
+    """The reference's correspondence list: point order, nearest then second nearest, absent neighbours skipped
+    (MatchPointCloud, …test.cc:320-340), truncated to floor(N/stride)*stride items.
+
+    stride = 4 is what the captured runs need: today's 3-DoF scalar class processes floor(N/4)*4 correspondences
+    (MDM/…_analytic_3dof.cc:33-36) and the captured 6-DoF scalar lines (results/maha_amd64_simple.txt:10-13,
+    maha_3_vs_6_amd64.txt:19-23, maha_amd64.txt:4-7 — the last identical to the 4-wide `SolveDoubleMatrix` lines
+    :10-13) are reproduced digit for digit with the same truncation and by nothing else, i.e. they were captured from
+    a revision whose 6-DoF scalar loop truncated as well."""
+    cols = np.nonzero((idx >= 0).reshape(-1))[0]
+    n = (cols.size // stride) * stride
+    return np.ascontiguousarray(planes[:, cols[:n]]), cols.size
+
+
+def captured_run_icp(solve_round, ndt_map, local_points, stride=4, max_outer=10):
+    """OptimizePoseAnalytic / OptimizePoseAnalytic3dof (…/simple_optimization_test.cc:474-503): ≤ 10 rounds of
+    {MatchPointCloud, Solve}, stop when |Δt| < 1e-5 and |vec(Δq)| < 1e-5.
+
+    solve_round(planes [15, n], R, t) → (R, t, printed_cost, iterations).  Returns (R, t, rounds, outer_iter) with
+    rounds = [(printed_cost, iterations, n_matches)]."""
+    from oracle import loader
+    R, t = np.eye(3), np.zeros(3)
+    lastR, lastt = R.copy(), t.copy()
+    rounds = []
+    outer = 0
+    for outer in range(max_outer):
+        planes, _, idx = match_point_cloud(ndt_map["means"], ndt_map["sqrt_infos"], ndt_map["valid"], local_points, R, t)
+        planes, n_matches = compact_correspondences(planes, idx, stride)
+        R, t, printed, iters = solve_round(planes, R, t)
+        R, t = np.asarray(R, dtype=np.float64).reshape(3, 3), np.asarray(t, dtype=np.float64).reshape(3)
+        rounds.append((float(printed), int(iters), int(n_matches)))
+        dR, dt = R.T @ lastR, R.T @ (lastt - t)
+        q = loader.quat_from_matrix(dR)
+        if np.linalg.norm(dt) < 1e-5 and np.linalg.norm(q[1:]) < 1e-5:
+            break
+        lastR, lastt = R.copy(), t.copy()
+    else:
+        outer = max_outer
+    return R, t, rounds, outer
+
+
+def printed(x):
+    """A double as `std::cerr << x` prints it (6 significant digits)."""
+    return "%.6g" % x

@@ -13,7 +13,7 @@ LOSS = ("exponential", 1.0, 1.0)
 @pytest.fixture(scope="module")
 def room():
     pts = scene.generate_global_points()
-    ndt = scene.build_ndt_map(pts, 1.0)
+    ndt = scene.build_ndt_map_eigen(pts, 1.0)  # Eigen's solver restated bit for bit: the reference's own map
     filtered = scene.filter_points(pts, 0.1)
     c, s = np.cos(0.1), np.sin(0.1)
     Rt = np.array([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]])
@@ -52,23 +52,21 @@ def test_scene_generator_known_answer_counts(room):
     assert scene.filter_points(room["points"], 0.05).shape[0] == 37711
 
 
-def test_oracle_icp_lands_in_the_reference_band(oracle, room):
-    """results/maha_amd64_simple.txt:10-13,24,26: inner solves `COST: 17438.4 / 17394.5 / 17490.6 /
-    17490.7` with 40, 40, 20, 2 iterations, outer_iter 3, final pose (-0.196416 0.121469 0.304836 | q z
-    0.0499568) vs true (-0.2 0.123 0.3 | 0.0499792).  Eigen's eigenvector sign convention enters S =
-    D^-1/2 V, so this is a band, not a bit golden: costs within 1.5 %, pose within 5 mm / 1e-3."""
+def test_oracle_icp_over_all_correspondences_stays_next_to_the_captured_run(oracle, room):
+    """results/maha_amd64_simple.txt:10-13,24,26: `COST: 17438.4 / 17394.5 / 17490.6 / 17490.7` with 40, 40, 20, 2
+    iterations, outer_iter 3.  tests/test_reference_ndt_runs.py reproduces these digit for digit with the captured
+    revision's floor(N/4)*4 truncation; THIS loop sums all N correspondences (what today's class and the GPU path do)
+    and uses LDLT: same iteration counts, costs higher by the ≤ 3 dropped (saturated, rho ≈ 1) correspondences."""
     R, t, rounds, outer = _oracle_icp(oracle, room)
-    assert 2 <= outer <= 5
-    assert rounds[0]["iterations"] == 40 and rounds[1]["iterations"] == 40
-    for r, ref in zip(rounds[:4], (17438.4, 17394.5, 17490.6, 17490.7)):
-        if r["printed_cost"] < 1e300:
-            assert abs(r["printed_cost"] - ref) / ref < 0.015, (r, ref)
-    assert 18000 <= rounds[0]["matches"] <= 2 * 9356
+    assert outer == 3
+    assert [r["iterations"] for r in rounds] == [40, 40, 20, 2]
+    for r, ref in zip(rounds, (17438.4, 17394.5, 17490.6, 17490.7)):
+        assert -0.1 <= r["printed_cost"] - ref <= 3.1, (r, ref)
+    assert rounds[0]["matches"] == 18307
     ref_t = np.array([-0.196416, 0.121469, 0.304836])
-    assert np.max(np.abs(t - ref_t)) < 5e-3
-    assert np.max(np.abs(t - room["t_true"])) < 6e-3
+    assert np.max(np.abs(t - ref_t)) < 5e-6
     q = oracle.quat_from_matrix(R)
-    assert abs(q[3] - 0.0499568) < 1e-3 and abs(q[0] - 0.998751) < 1e-4
+    assert abs(q[3] - 0.0499568) < 1e-6 and abs(q[0] - 0.998751) < 1e-6
 
 
 def test_zero_records_contribute_nothing(oracle):
@@ -143,7 +141,7 @@ def test_gpu_scan_to_map_matches_oracle_loop_and_reference_band(ctx, oracle, roo
             assert abs(a["printed_cost"] - b["printed_cost"]) <= 1e-9 * b["printed_cost"]
     dt, dq = helpers.pose_delta(pose.R, pose.t, R, t)
     assert dt < 1e-8 and dq < 1e-8, (dt, dq)
-    assert np.max(np.abs(pose.t - np.array([-0.196416, 0.121469, 0.304836]))) < 5e-3
+    assert np.max(np.abs(pose.t - np.array([-0.196416, 0.121469, 0.304836]))) < 5e-6  # results/maha_amd64_simple.txt:24
     sc.close()
     gm.close()
 
