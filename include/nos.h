@@ -110,9 +110,18 @@ int nos_ctx_synchronize(nos_ctx* ctx);
 int nos_comm_get_unique_id(unsigned char id[NOS_COMM_ID_BYTES]);
 int nos_ctx_comm_init(nos_ctx* ctx, int n_ranks, int rank, const unsigned char id[NOS_COMM_ID_BYTES]);
 int nos_ctx_comm_size(const nos_ctx* ctx); /* 0 if no communicator */
+/* Ranks RCCL itself reports for the context's communicator (ncclCommCount); *count = 0 without an RCCL communicator. */
+int nos_ctx_comm_rccl_count(const nos_ctx* ctx, int* count);
+/* One line of JSON: HIP version the library was built with, HIP runtime / driver version mapped into this process,
+ * the files the runtime and librccl were loaded from, RCCL's version, and two verdicts — "same_rocm_tree" (runtime and
+ * librccl come from one directory) and "runtime_matches_build" (major.minor).  librccl is bound on first use: from
+ * $NOS_RCCL_PATH, else from the directory of the HIP runtime already in the process, else the loader's default. */
+int nos_runtime_info(char* buf, size_t capacity);
 /* Alternative communicator for ranks on ONE node: a mailbox in POSIX shared memory (name, starting with '/',
- * chosen by the caller and identical on every rank; every rank creates-or-opens it, rank 0 may call
- * nos_comm_shm_unlink once all ranks have attached).  The sums are then exchanged INSIDE the launch: the workgroup
+ * chosen by the caller and identical on every rank).  Collective: rank 0 unlinks any segment of that name, creates a
+ * fresh one exclusively and acknowledges every other rank; the other ranks open the name (retrying) and accept a
+ * mapping only once rank 0 has acknowledged THEIR random hello word — a segment left behind by a crashed run is never
+ * joined (bounded by NOS_SHM_ATTACH_TIMEOUT_MS, default 30 s).  Rank 0 may call nos_comm_shm_unlink once all ranks have returned.  The sums are then exchanged INSIDE the launch: the workgroup
  * that completes a GPU's sums stores them in its mailbox slot, waits (bounded) for the other ranks' slots and adds
  * them in rank order, so nos_*_accumulate and nos_*_solve return identical bits on every rank with no extra
  * kernel, no RCCL call and no host step per iteration.  This is the reference's "sum the per-thread partials"
@@ -365,6 +374,23 @@ int nos_pgo_get_state(nos_pose_graph* pg, double* poses, double* switches);
 int nos_pgo_get_vector(nos_pose_graph* pg, int which, double* out);
 /* y = (J^T J with its diagonal scaled by 1 + lambda) x for host vectors.  Diagnostics. */
 int nos_pgo_matvec(nos_pose_graph* pg, double lambda, const double* x, double* y);
+
+/* ---- thread safety ----------------------------------------------------------------
+ * Every entry point that takes a context, or an object created on one (dataset, map, scan, pose graph), holds that
+ * context's lock for its whole duration: calls on ONE context are serialised, calls on different contexts run
+ * concurrently.  The drop-in solver classes share one context per device list, so two threads that each own a solver
+ * object are safe (their solves take turns) — the guarantee the reference's independent solver objects give.
+ * nos_ctx_destroy must not race with any other call on that context.
+ *
+ * ---- experiment knobs ----------------------------------------------------------------
+ * Read from the environment once, in nos_ctx_create (NOS_SC1, NOS_NT, NOS_FUSED, NOS_LM_FUSED, NOS_LM_WINDOW,
+ * NOS_LM_SINGLE, NOS_LM_CLUSTER, NOS_POOL, NOS_TILE_LOG2, NOS_PLANE_SKEW, NOS_INGEST, NOS_INGEST_THREADS,
+ * NOS_INDEXED_BPC, NOS_MATCH_DENSE, NOS_PGO_HOST_SCALARS, NOS_PGO_PRECOND); afterwards only through these setters (keys =
+ * the names in lower case without the prefix, e.g. "lm_cluster"; "ingest": 0 auto, 1 pack, 2 unpack;
+ * "debug_cluster_abort": test hook, makes the next one-launch solve give up and fall back).  Nothing on the solve /
+ * accumulate path reads the environment. */
+int nos_ctx_set_option(nos_ctx* ctx, const char* key, int value);
+int nos_ctx_get_option(const nos_ctx* ctx, const char* key, int* value);
 
 /* ---- measurement / diagnostics ------------------------------------------------- */
 /* Launch geometry override (0 = library default): blocks per CU of the assemble grid and

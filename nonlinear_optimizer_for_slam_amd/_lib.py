@@ -36,7 +36,8 @@ C_ABI_SYMBOLS = (
     "nos_ndt6_accumulate", "nos_ndt3_accumulate", "nos_reproj_accumulate",
     "nos_ndt6_accumulate_async", "nos_ndt3_accumulate_async", "nos_reproj_accumulate_async",
     "nos_ndt6_solve", "nos_ndt3_solve", "nos_reproj_solve",
-    "nos_ctx_set_launch", "nos_ctx_profile_begin", "nos_ctx_profile_end", "nos_ndt6_time_kernel", "nos_reproj_time_kernel",
+    "nos_ctx_set_launch", "nos_ctx_set_option", "nos_ctx_get_option", "nos_runtime_info", "nos_ctx_comm_rccl_count",
+    "nos_ctx_profile_begin", "nos_ctx_profile_end", "nos_ndt6_time_kernel", "nos_reproj_time_kernel",
     "nos_ndt3_time_kernel", "nos_status_string", "nos_last_error", "nos_version",
 )
 
@@ -93,6 +94,10 @@ def _declare(lib):
     lib.nos_ctx_set_stream.argtypes = [vp, i, vp]
     lib.nos_ctx_synchronize.argtypes = [vp]
     lib.nos_ctx_set_launch.argtypes = [vp, i, i]
+    lib.nos_ctx_set_option.argtypes = [vp, ctypes.c_char_p, i]
+    lib.nos_ctx_get_option.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(i)]
+    lib.nos_runtime_info.argtypes = [ctypes.c_char_p, sz]
+    lib.nos_ctx_comm_rccl_count.argtypes = [vp, ctypes.POINTER(i)]
     lib.nos_comm_get_unique_id.argtypes = [ctypes.c_char_p]
     lib.nos_ctx_comm_init.argtypes = [vp, i, i, ctypes.c_char_p]
     lib.nos_ctx_comm_init_shm.argtypes = [vp, i, i, ctypes.c_char_p]

@@ -45,6 +45,14 @@ def _dp(a):
     return a.ctypes.data_as(c_double_p)
 
 
+def runtime_info():
+    """Where the HIP runtime and librccl mapped into this process come from (nos_runtime_info) → dict."""
+    import json
+    buf = ctypes.create_string_buffer(4096)
+    check(hip_lib().nos_runtime_info(buf, 4096), "nos_runtime_info")
+    return json.loads(buf.value.decode())
+
+
 def new_unique_id():
     """128-byte RCCL unique id (rank 0 creates it, all ranks pass it to Context.comm_init)."""
     buf = ctypes.create_string_buffer(128)
@@ -84,6 +92,38 @@ class Context:
 
     def set_launch(self, blocks_per_cu=0, variant=0):
         check(self._lib.nos_ctx_set_launch(self._h, blocks_per_cu, variant), "nos_ctx_set_launch")
+
+    def set_option(self, key, value):
+        """Experiment knob of the context (include/nos.h, "experiment knobs"): e.g. set_option("lm_cluster", 0)."""
+        check(self._lib.nos_ctx_set_option(self._h, key.encode(), int(value)), "nos_ctx_set_option")
+
+    def get_option(self, key):
+        v = ctypes.c_int()
+        check(self._lib.nos_ctx_get_option(self._h, key.encode(), ctypes.byref(v)), "nos_ctx_get_option")
+        return v.value
+
+    def options(self, **kv):
+        """with ctx.options(lm_cluster=0, lm_single=0): ... — set for the block, restored afterwards."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            old = {k: self.get_option(k) for k in kv}
+            try:
+                for k, v in kv.items():
+                    self.set_option(k, v)
+                yield self
+            finally:
+                for k, v in old.items():
+                    self.set_option(k, v)
+        return scope()
+
+    @property
+    def comm_rccl_count(self):
+        """Ranks RCCL reports for this context's communicator (ncclCommCount); 0 without an RCCL communicator."""
+        v = ctypes.c_int()
+        check(self._lib.nos_ctx_comm_rccl_count(self._h, ctypes.byref(v)), "nos_ctx_comm_rccl_count")
+        return v.value
 
     def comm_init(self, n_ranks, rank, unique_id):
         """Collective: join the RCCL communicator identified by the 128-byte unique_id."""

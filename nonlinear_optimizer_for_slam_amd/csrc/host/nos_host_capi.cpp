@@ -321,6 +321,39 @@ int nos_host_ndt6_iterate(nos_dataset* dataset, const nos_loss* loss, int iterat
   return lm.ok ? 1 : 0;
 }
 
+// planar loop: t = (t_x, t_y, ·), R row-major 3x3 of which the top-left 2x2 is used and written back
+// (MDM/…_analytic_3dof.cc:23-25,104-105)
+int nos_host_ndt3_iterate(nos_dataset* dataset, const nos_loss* loss, int iterations, double t[3], double R[9],
+                          double report[5]) {
+  nos_host::LmSettings s;
+  s.max_iterations = iterations;
+  s.gradient_tolerance = 0.0;
+  s.parameter_tolerance = 0.0;
+  int status = NOS_OK;
+  double R2[4] = {R[0], R[1], R[3], R[4]}, t2[2] = {t[0], t[1]};
+  const nos_host::LmReport lm = nos_host::RunLm3(
+      s,
+      [&](const double* Rc, const double* tc, double* out) {
+        status = nos_ndt3_accumulate(dataset, Rc, tc, loss, out);
+        return status == NOS_OK;
+      },
+      t2, R2);
+  R[0] = R2[0];
+  R[1] = R2[1];
+  R[3] = R2[2];
+  R[4] = R2[3];
+  t[0] = t2[0];
+  t[1] = t2[1];
+  if (report != nullptr) {
+    report[0] = lm.iterations;
+    report[1] = lm.printed_cost;
+    report[2] = lm.last_cost;
+    report[3] = lm.final_lambda;
+    report[4] = status;
+  }
+  return lm.ok ? 1 : 0;
+}
+
 int nos_host_reproj_iterate(nos_dataset* dataset, const double intr[4], const nos_loss* loss, double min_depth,
                             int iterations, double t[3], double R[9], double report[5]) {
   nos_host::LmSettings s;

@@ -23,14 +23,38 @@ int fail(int status, const char* fmt, ...) {
 
 const char* last_error_text() { return g_last_error.c_str(); }
 
+// Directory of the shared object that provides `symbol` in this process ("" if unknown).
+static std::string dir_of_symbol(const void* symbol, std::string* file_out = nullptr) {
+  Dl_info info{};
+  if (symbol == nullptr || dladdr(symbol, &info) == 0 || info.dli_fname == nullptr) return std::string();
+  char resolved[PATH_MAX];
+  std::string file = realpath(info.dli_fname, resolved) ? std::string(resolved) : std::string(info.dli_fname);
+  if (file_out) *file_out = file;
+  const size_t slash = file.rfind('/');
+  return slash == std::string::npos ? std::string() : file.substr(0, slash);
+}
+
+// librccl is bound with dlopen on first use.  Search order: $NOS_RCCL_PATH, then the librccl that sits NEXT TO the HIP
+// runtime already mapped into the process (so runtime and collectives always come from one ROCm tree — a process that
+// imported torch first runs on torch's bundled runtime and gets torch's bundled librccl; one that did not gets the
+// system pair), then the loader's default search.
 RcclApi* Rccl() {
   static RcclApi api;
   static bool tried = false;
   if (tried) return &api;
   tried = true;
-  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-  for (const char* n : names) {
-    api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+  std::vector<std::string> names;
+  if (const char* forced = getenv("NOS_RCCL_PATH")) names.push_back(forced);
+  const std::string hip_dir = dir_of_symbol(reinterpret_cast<const void*>(&hipGetDeviceCount));
+  if (!hip_dir.empty()) {
+    names.push_back(hip_dir + "/librccl.so.1");
+    names.push_back(hip_dir + "/librccl.so");
+  }
+  names.push_back("librccl.so.1");
+  names.push_back("librccl.so");
+  names.push_back("/opt/rocm/lib/librccl.so.1");
+  for (const std::string& n : names) {
+    api.handle = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL);
     if (api.handle) break;
   }
   if (!api.handle) return &api;
@@ -39,7 +63,10 @@ RcclApi* Rccl() {
   api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.handle, "ncclCommDestroy"));
   api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(api.handle, "ncclAllReduce"));
   api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.handle, "ncclGetErrorString"));
+  api.CommCount = reinterpret_cast<decltype(api.CommCount)>(dlsym(api.handle, "ncclCommCount"));
+  api.GetVersion = reinterpret_cast<decltype(api.GetVersion)>(dlsym(api.handle, "ncclGetVersion"));
   api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllReduce && api.GetErrorString;
+  if (api.ok) dir_of_symbol(reinterpret_cast<const void*>(api.AllReduce), &api.path);
   return &api;
 }
 
@@ -56,7 +83,7 @@ int env_int(const char* name, int dflt) {
 
 // ------------------------------------------------------------------ layout
 
-nos::TiledLayout make_layout(size_t n, int n_fields, int tile_log2) {
+nos::TiledLayout make_layout(size_t n, int n_fields, int tile_log2, int plane_skew) {
   nos::TiledLayout L{};
   L.n = n;
   if (tile_log2 <= 0) {
@@ -67,7 +94,7 @@ nos::TiledLayout make_layout(size_t n, int n_fields, int tile_log2) {
     L.tile_stride = 0;
     // planes are skewed against each other so that the 15 concurrent streams of a block never start at the same
     // offset modulo a large power of two (n_padded itself often is one)
-    L.field_stride = L.n_padded + size_t(env_int("NOS_PLANE_SKEW", 1088));
+    L.field_stride = L.n_padded + size_t(plane_skew);
     L.tile_shift = 40;
     L.tile_mask = 0xFFFFFFFFu;
   } else {
@@ -107,7 +134,7 @@ int launch_variant(const nos::TiledLayout& L, const typename Problem::Params& P,
   if (grid > kMaxPartialRows) grid = kMaxPartialRows;
   nos::FusedFinal fin = fin_in;
   // write-through hand-off only in the geometry it is documented valid for: at most one workgroup per CU
-  fin.write_through = (fin.counter != nullptr && grid <= num_cus_hint && env_int("NOS_SC1", 1) != 0) ? 1 : 0;
+  fin.write_through = (fin.counter != nullptr && grid <= num_cus_hint && fin_in.write_through != 0) ? 1 : 0;  // in: allowed (settings.sc1)
   if (nt)
     hipLaunchKernelGGL((nos::assemble_kernel<Problem, T, ITEMS, BLOCK, MINW, true, PREFETCH>), dim3(grid), dim3(BLOCK), 0,
                        stream, L, P, n_chunks, partials, fin);
@@ -234,9 +261,8 @@ int check_loss(const nos_loss* loss, int* kind_out) {
 // Streaming (non-temporal) loads when the shard cannot stay resident in the 256 MiB
 // Infinity Cache between iterations; default-policy loads when it can.
 bool use_nontemporal(const nos_dataset* ds, const Shard& sh) {
-  const int force = env_int("NOS_NT", -1);
+  const int force = ds->ctx->settings.nt;
   if (force >= 0) return force != 0;
-  (void)ds;
   return sh.bytes > (size_t(192) << 20);
 }
 
@@ -263,9 +289,11 @@ int launch_assemble(const nos_dataset* ds, const Shard& sh, const Request& rq, d
 }
 
 int launch_assemble_raw(const nos_dataset* ds, const Shard& sh, const Request& rq, double* partials,
-                        const nos::FusedFinal& fin, hipStream_t stream, int* rows_out, const SingleBlockArgs* single) {
-  if (ds->kind == kKindNdtIndexed) return launch_indexed(ds, sh, rq, partials, fin, stream, rows_out);
+                        const nos::FusedFinal& fin_in, hipStream_t stream, int* rows_out, const SingleBlockArgs* single) {
   const nos_ctx* ctx = ds->ctx;
+  nos::FusedFinal fin = fin_in;
+  fin.write_through = ctx->settings.sc1;  // "allowed"; the launcher keeps it only for the geometry it is valid for
+  if (ds->kind == kKindNdtIndexed) return launch_indexed(ds, sh, rq, partials, fin, stream, rows_out);
   const DeviceSlot& slot = ctx->slots[sh.slot];
   const bool nt = use_nontemporal(ds, sh);
   const int variant = ctx->variant;
@@ -426,7 +454,7 @@ int wait_for_sequence(DeviceSlot& slot) { return wait_for_sequence(slot, slot.se
 // (the reference sums its per-thread partials the same way).
 int accumulate_sync(nos_dataset* ds, const Request& rq, double* out) {
   nos_ctx* ctx = ds->ctx;
-  const bool fused = env_int("NOS_FUSED", 1) != 0 || ctx->shm_dev != nullptr;  // the mailbox exchange lives in the fused tail
+  const bool fused = ctx->settings.fused != 0 || ctx->shm_dev != nullptr;  // the mailbox exchange lives in the fused tail
   if (ctx->comm != nullptr) {
     // one process per GPU: local sums → RCCL all-reduce of the n_out doubles (in place, on the
     // same stream) → publish to pinned host memory.  Every rank receives identical bits.
@@ -498,7 +526,7 @@ int accumulate_async(nos_dataset* ds, const Request& rq, double* d_out) {
     NOS_RCCL_CHECK(Rccl()->AllReduce(d_out, d_out, size_t(rq.n_out), ncclDouble, ncclSum, ctx->comm, slot.stream));
     return NOS_OK;
   }
-  if (env_int("NOS_FUSED", 1) != 0 || ctx->shm_dev != nullptr) {
+  if (ctx->settings.fused != 0 || ctx->shm_dev != nullptr) {
     nos::FusedFinal fin{slot.counter, d_out, nullptr, nullptr, 0};
     fin.mail = ctx->d_mail;
     return launch_assemble(ds, sh, rq, slot.partials, fin, slot.stream, &rows);
@@ -516,7 +544,7 @@ int time_kernel(nos_dataset* ds, const Request& rq, int repeats, double* kernel_
   NOS_HIP_CHECK(hipSetDevice(slot.device));
   int rows = 0;
   // warm-up
-  const bool fused = env_int("NOS_FUSED", 1) != 0;
+  const bool fused = ctx->settings.fused != 0;
   for (int i = 0; i < 2; ++i) {
     int rc = launch_assemble(ds, sh, rq, slot.partials, nos::FusedFinal{}, slot.stream, &rows);
     if (rc != NOS_OK) return rc;
@@ -564,8 +592,8 @@ int lm_solve(nos_dataset* ds, const Request& rq, const nos_lm_options* opt, doub
   DeviceSlot& slot = ctx->slots[sh.slot];
   NOS_HIP_CHECK(hipSetDevice(slot.device));
   const bool with_comm = ctx->comm != nullptr;
-  const bool step_in_launch = !with_comm && env_int("NOS_LM_FUSED", 1) != 0;
-  int window = opt->launches_in_flight > 0 ? opt->launches_in_flight : env_int("NOS_LM_WINDOW", 3);
+  const bool step_in_launch = !with_comm && ctx->settings.lm_fused != 0;
+  int window = opt->launches_in_flight > 0 ? opt->launches_in_flight : ctx->settings.lm_window;
   window = std::max(1, std::min(window, kLogSlots - 2));
 
   nos::LmInitArgs init{};
@@ -586,7 +614,7 @@ int lm_solve(nos_dataset* ds, const Request& rq, const nos_lm_options* opt, doub
   unsigned long long* seq_dev = reinterpret_cast<unsigned long long*>(slot.h_out_dev + kSeqSlot);
   // Small problems: the whole loop in one workgroup and one launch (see nos::solve_single_block_kernel)
   if (ds->kind != kKindNdtIndexed && !with_comm && ctx->shm_dev == nullptr && opt->max_iterations > 0 &&
-      sh.layout.n * size_t(ds->n_fields) <= nos::kSingleBlockMaxElements && env_int("NOS_LM_SINGLE", 1) != 0 &&
+      sh.layout.n * size_t(ds->n_fields) <= nos::kSingleBlockMaxElements && ctx->settings.lm_single != 0 &&
       (opt->cost_history == nullptr || opt->max_iterations <= kHistCapacity)) {
     SingleBlockArgs single{};
     single.lm = slot.d_lm;
@@ -632,7 +660,7 @@ int lm_solve(nos_dataset* ds, const Request& rq, const nos_lm_options* opt, doub
   const size_t cluster_blocks = (sh.layout.n + 511) / 512;
   if (ds->kind != kKindNdtIndexed && !with_comm && ctx->shm_dev == nullptr && opt->max_iterations > 0 &&
       cluster_blocks >= 1 && cluster_blocks <= nos::kClusterMaxBlocks && cluster_blocks <= size_t(slot.num_cus) &&
-      env_int("NOS_LM_CLUSTER", 1) != 0 && (opt->cost_history == nullptr || opt->max_iterations <= kHistCapacity)) {
+      ctx->settings.lm_cluster != 0 && (opt->cost_history == nullptr || opt->max_iterations <= kHistCapacity)) {
     SingleBlockArgs cl{};
     cl.cluster_blocks = int(cluster_blocks);
     cl.partials = slot.partials;
@@ -645,7 +673,7 @@ int lm_solve(nos_dataset* ds, const Request& rq, const nos_lm_options* opt, doub
     cl.entry = slot.h_log_dev;
     cl.seq_host = seq_dev;
     cl.seq = ++slot.seq;
-    if (env_int("NOS_TEST_CLUSTER_ABORT", 0) != 0) {  // test hook: the launch finds `abort` already raised and gives up
+    if (ctx->settings.debug_cluster_abort != 0) {  // test hook (nos_ctx_set_option): the launch finds `abort` already raised and gives up
       const nos::ClusterCtl raised{slot.cluster_epoch, 1u};
       NOS_HIP_CHECK(hipMemcpyAsync(slot.d_cluster, &raised, sizeof raised, hipMemcpyHostToDevice, slot.stream));
       NOS_HIP_CHECK(hipStreamSynchronize(slot.stream));
@@ -831,7 +859,7 @@ int pool_alloc(DeviceSlot& slot, size_t bytes, void** ptr, size_t* capacity) {
 
 void pool_release(DeviceSlot& slot, void* ptr, size_t capacity) {
   if (!ptr) return;
-  if (env_int("NOS_POOL", 1) == 0 || capacity > kPoolMaxBytes) {
+  if (!slot.pool_enabled || capacity > kPoolMaxBytes) {
     (void)hipFree(ptr);
     return;
   }
@@ -848,7 +876,7 @@ int alloc_shards(nos_ctx* ctx, nos_dataset* ds) {
   const int n_shards = int(ctx->slots.size());
   const size_t n = ds->n;
   const size_t per = (n + n_shards - 1) / size_t(n_shards);  // contiguous equal ranges
-  int tile_log2 = ctx->tile_log2 >= 0 ? ctx->tile_log2 : env_int("NOS_TILE_LOG2", int(kDefaultTileLog2));
+  int tile_log2 = ctx->tile_log2 >= 0 ? ctx->tile_log2 : ctx->settings.tile_log2;
   if (tile_log2 != 0 && (tile_log2 < 10 || tile_log2 > 24)) return fail(NOS_ERR_INVALID_ARGUMENT, "tile_log2 out of range");
   ds->tile = tile_log2 > 0 ? (size_t(1) << tile_log2) : 0;
   ds->shards.resize(n_shards);
@@ -857,7 +885,7 @@ int alloc_shards(nos_ctx* ctx, nos_dataset* ds) {
     const size_t cnt = begin < n ? std::min(per, n - begin) : 0;
     Shard& sh = ds->shards[s];
     sh.slot = s;
-    sh.layout = make_layout(cnt, ds->n_fields, tile_log2);
+    sh.layout = make_layout(cnt, ds->n_fields, tile_log2, ctx->settings.plane_skew);
     sh.bytes = layout_elems(sh.layout, ds->n_fields) * elem_size(ds->dtype);
     NOS_HIP_CHECK(hipSetDevice(ctx->slots[s].device));
     int prc = pool_alloc(ctx->slots[s], sh.bytes, &sh.data, &sh.capacity);
@@ -1118,10 +1146,9 @@ int create_from_records(nos_ctx* ctx, int kind, size_t n, const void* records, s
   // Which ingestion: "unpack" ships the raw records and unpacks on the device (no host work, 304 B/record over PCIe);
   // "pack" gathers on the host with a few threads and ships planes (120 / 60 B/record).  auto = pack for large planar
   // inputs when the host has threads to spare (NOS_INGEST=pack|unpack forces, NOS_INGEST_THREADS sets the count).
-  const char* mode_env = getenv("NOS_INGEST");
-  const std::string mode = mode_env ? mode_env : "auto";
+  const std::string mode = ctx->settings.ingest == 1 ? "pack" : (ctx->settings.ingest == 2 ? "unpack" : "auto");
   const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-  int pack_threads = env_int("NOS_INGEST_THREADS", int(std::min(16u, hw / 2)));
+  int pack_threads = ctx->settings.ingest_threads > 0 ? ctx->settings.ingest_threads : int(std::min(16u, hw / 2));
   const bool planar = ds->tile == 0;
   const bool use_pack = planar && pack_threads >= 1 &&
                         (mode == "pack" || (mode == "auto" && n >= size_t(800000) && pack_threads >= 8));
@@ -1232,9 +1259,30 @@ int nos_ctx_create(const int* device_ids, int n_devices, nos_ctx** out_ctx) {
   ctx->slots.resize(n_devices);
   ctx->blocks_per_cu = env_int("NOS_BLOCKS_PER_CU", 0);
   ctx->variant = env_int("NOS_VARIANT", 0);
+  {  // the only place the experiment knobs are read from the environment
+    Settings& st = ctx->settings;
+    st.plane_skew = env_int("NOS_PLANE_SKEW", st.plane_skew);
+    st.sc1 = env_int("NOS_SC1", st.sc1);
+    st.nt = env_int("NOS_NT", st.nt);
+    st.fused = env_int("NOS_FUSED", st.fused);
+    st.lm_fused = env_int("NOS_LM_FUSED", st.lm_fused);
+    st.lm_window = env_int("NOS_LM_WINDOW", st.lm_window);
+    st.lm_single = env_int("NOS_LM_SINGLE", st.lm_single);
+    st.lm_cluster = env_int("NOS_LM_CLUSTER", st.lm_cluster);
+    st.pool = env_int("NOS_POOL", st.pool);
+    st.tile_log2 = env_int("NOS_TILE_LOG2", int(kDefaultTileLog2));
+    const char* ingest = getenv("NOS_INGEST");
+    st.ingest = (ingest && !strcmp(ingest, "pack")) ? 1 : ((ingest && !strcmp(ingest, "unpack")) ? 2 : 0);
+    st.ingest_threads = env_int("NOS_INGEST_THREADS", 0);
+    st.indexed_bpc = env_int("NOS_INDEXED_BPC", st.indexed_bpc);
+    st.match_dense = env_int("NOS_MATCH_DENSE", st.match_dense);
+    st.pgo_host_scalars = env_int("NOS_PGO_HOST_SCALARS", st.pgo_host_scalars);
+    st.pgo_precond = env_int("NOS_PGO_PRECOND", st.pgo_precond);
+  }
   for (int i = 0; i < n_devices; ++i) {
     DeviceSlot& s = ctx->slots[i];
     s.device = device_ids[i];
+    s.pool_enabled = ctx->settings.pool != 0;
     hipDeviceProp_t prop;
     e = hipSetDevice(s.device);
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, s.device);
@@ -1273,6 +1321,7 @@ int nos_ctx_create(const int* device_ids, int n_devices, nos_ctx** out_ctx) {
 }
 
 int nos_ctx_comm_destroy(nos_ctx* ctx) {
+  nosd::CtxGuard guard_(ctx);  // one solve / accumulate / create at a time per context
   if (!ctx) return NOS_OK;
   if (ctx->comm != nullptr) {
     if (!ctx->slots.empty()) {
@@ -1345,12 +1394,14 @@ int nos_ctx_destroy(nos_ctx* ctx) {
 int nos_ctx_num_devices(const nos_ctx* ctx) { return ctx ? int(ctx->slots.size()) : 0; }
 
 int nos_ctx_set_stream(nos_ctx* ctx, int shard, void* hip_stream) {
+  nosd::CtxGuard guard_(ctx);  // one solve / accumulate / create at a time per context
   if (!ctx || shard < 0 || shard >= int(ctx->slots.size())) return fail(NOS_ERR_INVALID_ARGUMENT, "bad ctx / shard");
   ctx->slots[shard].stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->slots[shard].own_stream;
   return NOS_OK;
 }
 
 int nos_ctx_synchronize(nos_ctx* ctx) {
+  nosd::CtxGuard guard_(ctx);  // one solve / accumulate / create at a time per context
   if (!ctx) return fail(NOS_ERR_INVALID_ARGUMENT, "ctx is NULL");
   for (DeviceSlot& s : ctx->slots) {
     NOS_HIP_CHECK(hipSetDevice(s.device));
@@ -1359,7 +1410,86 @@ int nos_ctx_synchronize(nos_ctx* ctx) {
   return NOS_OK;
 }
 
+namespace {
+struct OptionEntry {
+  const char* key;
+  int nosd::Settings::*field;
+};
+const OptionEntry kOptions[] = {
+    {"plane_skew", &nosd::Settings::plane_skew}, {"sc1", &nosd::Settings::sc1}, {"nt", &nosd::Settings::nt},
+    {"fused", &nosd::Settings::fused}, {"lm_fused", &nosd::Settings::lm_fused}, {"lm_window", &nosd::Settings::lm_window},
+    {"lm_single", &nosd::Settings::lm_single}, {"lm_cluster", &nosd::Settings::lm_cluster}, {"pool", &nosd::Settings::pool},
+    {"tile_log2", &nosd::Settings::tile_log2}, {"ingest", &nosd::Settings::ingest},
+    {"ingest_threads", &nosd::Settings::ingest_threads}, {"indexed_bpc", &nosd::Settings::indexed_bpc},
+    {"match_dense", &nosd::Settings::match_dense}, {"pgo_host_scalars", &nosd::Settings::pgo_host_scalars},
+    {"pgo_precond", &nosd::Settings::pgo_precond}, {"debug_cluster_abort", &nosd::Settings::debug_cluster_abort},
+};
+}  // namespace
+
+int nos_ctx_set_option(nos_ctx* ctx, const char* key, int value) {
+  if (!ctx || !key) return fail(NOS_ERR_INVALID_ARGUMENT, "ctx / key is NULL");
+  nosd::CtxGuard guard_(ctx);
+  for (const OptionEntry& o : kOptions)
+    if (!strcmp(o.key, key)) {
+      ctx->settings.*(o.field) = value;
+      for (DeviceSlot& s : ctx->slots) s.pool_enabled = ctx->settings.pool != 0;
+      return NOS_OK;
+    }
+  return fail(NOS_ERR_INVALID_ARGUMENT, "unknown option '%s'", key);
+}
+
+int nos_ctx_get_option(const nos_ctx* ctx, const char* key, int* value) {
+  if (!ctx || !key || !value) return fail(NOS_ERR_INVALID_ARGUMENT, "ctx / key / value is NULL");
+  nosd::CtxGuard guard_(ctx);
+  for (const OptionEntry& o : kOptions)
+    if (!strcmp(o.key, key)) {
+      *value = ctx->settings.*(o.field);
+      return NOS_OK;
+    }
+  return fail(NOS_ERR_INVALID_ARGUMENT, "unknown option '%s'", key);
+}
+
+// Where the HIP runtime and the collectives library mapped into this process come from, and whether that is the ROCm
+// the library was built with.  One line of JSON.
+int nos_runtime_info(char* buf, size_t capacity) {
+  if (!buf || capacity == 0) return fail(NOS_ERR_INVALID_ARGUMENT, "buf is NULL");
+  int runtime = 0, driver = 0;
+  (void)hipRuntimeGetVersion(&runtime);
+  (void)hipDriverGetVersion(&driver);
+  std::string hip_file;
+  const std::string hip_dir = dir_of_symbol(reinterpret_cast<const void*>(&hipGetDeviceCount), &hip_file);
+  RcclApi* api = Rccl();
+  int rccl_version = 0;
+  if (api->ok && api->GetVersion) (void)api->GetVersion(&rccl_version);
+  const std::string rccl_file = api->ok ? api->path : std::string();
+  const size_t slash = rccl_file.rfind('/');
+  const std::string rccl_dir = slash == std::string::npos ? std::string() : rccl_file.substr(0, slash);
+  const int build = HIP_VERSION;  // major * 10^7 + minor * 10^5 + patch, same encoding as hipRuntimeGetVersion
+  const int n = snprintf(buf, capacity,
+                         "{\"build_hip_version\": %d, \"runtime_hip_version\": %d, \"driver_version\": %d, "
+                         "\"hip_runtime_path\": \"%s\", \"rccl_path\": \"%s\", \"rccl_version\": %d, "
+                         "\"same_rocm_tree\": %s, \"runtime_matches_build\": %s}",
+                         build, runtime, driver, hip_file.c_str(), rccl_file.c_str(), rccl_version,
+                         (!rccl_dir.empty() && rccl_dir == hip_dir) ? "true" : "false",
+                         (build / 100000 == runtime / 100000) ? "true" : "false");
+  if (n < 0 || size_t(n) >= capacity) return fail(NOS_ERR_INVALID_ARGUMENT, "buffer too small");
+  return NOS_OK;
+}
+
+// Number of ranks RCCL itself reports for the context's communicator (ncclCommCount); 0 without an RCCL communicator.
+int nos_ctx_comm_rccl_count(const nos_ctx* ctx, int* count) {
+  if (!ctx || !count) return fail(NOS_ERR_INVALID_ARGUMENT, "ctx / count is NULL");
+  nosd::CtxGuard guard_(ctx);
+  *count = 0;
+  if (ctx->comm == nullptr) return NOS_OK;
+  RcclApi* api = Rccl();
+  if (!api->ok || !api->CommCount) return fail(NOS_ERR_UNSUPPORTED, "ncclCommCount unavailable");
+  NOS_RCCL_CHECK(api->CommCount(ctx->comm, count));
+  return NOS_OK;
+}
+
 int nos_ctx_set_launch(nos_ctx* ctx, int blocks_per_cu, int variant) {
+  nosd::CtxGuard guard_(ctx);  // one solve / accumulate / create at a time per context
   if (!ctx) return fail(NOS_ERR_INVALID_ARGUMENT, "ctx is NULL");
   if (blocks_per_cu < 0 || blocks_per_cu > 32 || variant < 0 || variant >= kNumVariants)
     return fail(NOS_ERR_INVALID_ARGUMENT, "launch override out of range");
@@ -1370,37 +1500,44 @@ int nos_ctx_set_launch(nos_ctx* ctx, int blocks_per_cu, int variant) {
 
 int nos_ndt_dataset_create(nos_ctx* ctx, size_t n, const double* const planes[NOS_NDT_PLANES], int dtype,
                            nos_dataset** out_ds) {
+  nosd::CtxGuard guard_(ctx);  // one solve / accumulate / create at a time per context
   return create_from_host_planes(ctx, kKindNdt, n, planes, dtype, out_ds);
 }
 
 int nos_reproj_dataset_create(nos_ctx* ctx, size_t n, const double* const planes[NOS_REPROJ_PLANES], int dtype,
                               nos_dataset** out_ds) {
+  nosd::CtxGuard guard_(ctx);  // one solve / accumulate / create at a time per context
   return create_from_host_planes(ctx, kKindReproj, n, planes, dtype, out_ds);
 }
 
 int nos_ndt_dataset_create_from_device(nos_ctx* ctx, size_t n, const void* const d_planes[NOS_NDT_PLANES],
                                        int src_dtype, int dtype, nos_dataset** out_ds) {
+  nosd::CtxGuard guard_(ctx);  // one solve / accumulate / create at a time per context
   return create_from_device_planes(ctx, kKindNdt, n, d_planes, src_dtype, dtype, out_ds);
 }
 
 int nos_reproj_dataset_create_from_device(nos_ctx* ctx, size_t n, const void* const d_planes[NOS_REPROJ_PLANES],
                                           int src_dtype, int dtype, nos_dataset** out_ds) {
+  nosd::CtxGuard guard_(ctx);  // one solve / accumulate / create at a time per context
   return create_from_device_planes(ctx, kKindReproj, n, d_planes, src_dtype, dtype, out_ds);
 }
 
 int nos_ndt_dataset_create_from_records(nos_ctx* ctx, size_t n, const void* records, size_t stride_bytes,
                                         const size_t field_offsets[NOS_NDT_PLANES], int dtype,
                                         nos_dataset** out_ds) {
+  nosd::CtxGuard guard_(ctx);  // one solve / accumulate / create at a time per context
   return create_from_records(ctx, kKindNdt, n, records, stride_bytes, field_offsets, dtype, out_ds);
 }
 
 int nos_reproj_dataset_create_from_records(nos_ctx* ctx, size_t n, const void* records, size_t stride_bytes,
                                            const size_t field_offsets[NOS_REPROJ_PLANES], int dtype,
                                            nos_dataset** out_ds) {
+  nosd::CtxGuard guard_(ctx);  // one solve / accumulate / create at a time per context
   return create_from_records(ctx, kKindReproj, n, records, stride_bytes, field_offsets, dtype, out_ds);
 }
 
 int nos_dataset_destroy(nos_dataset* ds) {
+  nosd::CtxGuard guard_(ds ? ds->ctx : nullptr);  // one solve / accumulate / create at a time per context
   if (!ds) return NOS_OK;
   for (Shard& sh : ds->shards) {
     if (sh.data || sh.index || sh.table) (void)hipSetDevice(ds->ctx->slots[sh.slot].device);
@@ -1431,6 +1568,7 @@ size_t nos_dataset_stream_bytes(const nos_dataset* ds) {
 
 int nos_ndt6_accumulate(nos_dataset* ds, const double R[9], const double t[3], const nos_loss* loss,
                         double out28[NOS_NDT6_OUT]) {
+  nosd::CtxGuard guard_(ds ? ds->ctx : nullptr);  // one solve / accumulate / create at a time per context
   Request rq;
   int rc = build_request(6, ds, R, 9, t, 3, nullptr, 0.0, loss, &rq);
   if (rc != NOS_OK) return rc;
@@ -1440,6 +1578,7 @@ int nos_ndt6_accumulate(nos_dataset* ds, const double R[9], const double t[3], c
 
 int nos_ndt3_accumulate(nos_dataset* ds, const double R2[4], const double t2[2], const nos_loss* loss,
                         double out10[NOS_NDT3_OUT]) {
+  nosd::CtxGuard guard_(ds ? ds->ctx : nullptr);  // one solve / accumulate / create at a time per context
   Request rq;
   int rc = build_request(3, ds, R2, 4, t2, 2, nullptr, 0.0, loss, &rq);
   if (rc != NOS_OK) return rc;
@@ -1449,6 +1588,7 @@ int nos_ndt3_accumulate(nos_dataset* ds, const double R2[4], const double t2[2],
 
 int nos_reproj_accumulate(nos_dataset* ds, const double R[9], const double t[3], const double intr[4],
                           const nos_loss* loss, double min_depth, double out28[NOS_REPROJ_OUT]) {
+  nosd::CtxGuard guard_(ds ? ds->ctx : nullptr);  // one solve / accumulate / create at a time per context
   Request rq;
   int rc = build_request(2, ds, R, 9, t, 3, intr, min_depth, loss, &rq);
   if (rc != NOS_OK) return rc;
@@ -1458,6 +1598,7 @@ int nos_reproj_accumulate(nos_dataset* ds, const double R[9], const double t[3],
 
 int nos_ndt6_accumulate_async(nos_dataset* ds, const double R[9], const double t[3], const nos_loss* loss,
                               double* d_out28) {
+  nosd::CtxGuard guard_(ds ? ds->ctx : nullptr);  // one solve / accumulate / create at a time per context
   Request rq;
   int rc = build_request(6, ds, R, 9, t, 3, nullptr, 0.0, loss, &rq);
   if (rc != NOS_OK) return rc;
@@ -1466,6 +1607,7 @@ int nos_ndt6_accumulate_async(nos_dataset* ds, const double R[9], const double t
 
 int nos_ndt3_accumulate_async(nos_dataset* ds, const double R2[4], const double t2[2], const nos_loss* loss,
                               double* d_out10) {
+  nosd::CtxGuard guard_(ds ? ds->ctx : nullptr);  // one solve / accumulate / create at a time per context
   Request rq;
   int rc = build_request(3, ds, R2, 4, t2, 2, nullptr, 0.0, loss, &rq);
   if (rc != NOS_OK) return rc;
@@ -1474,6 +1616,7 @@ int nos_ndt3_accumulate_async(nos_dataset* ds, const double R2[4], const double 
 
 int nos_reproj_accumulate_async(nos_dataset* ds, const double R[9], const double t[3], const double intr[4],
                                 const nos_loss* loss, double min_depth, double* d_out28) {
+  nosd::CtxGuard guard_(ds ? ds->ctx : nullptr);  // one solve / accumulate / create at a time per context
   Request rq;
   int rc = build_request(2, ds, R, 9, t, 3, intr, min_depth, loss, &rq);
   if (rc != NOS_OK) return rc;
@@ -1482,6 +1625,7 @@ int nos_reproj_accumulate_async(nos_dataset* ds, const double R[9], const double
 
 int nos_ndt6_solve(nos_dataset* ds, double R[9], double t[3], const nos_loss* loss, const nos_lm_options* options,
                    nos_lm_report* report) {
+  nosd::CtxGuard guard_(ds ? ds->ctx : nullptr);  // one solve / accumulate / create at a time per context
   Request rq;
   int rc = build_request(6, ds, R, 9, t, 3, nullptr, 0.0, loss, &rq);
   if (rc != NOS_OK) return rc;
@@ -1490,6 +1634,7 @@ int nos_ndt6_solve(nos_dataset* ds, double R[9], double t[3], const nos_loss* lo
 
 int nos_ndt3_solve(nos_dataset* ds, double R2[4], double t2[2], const nos_loss* loss, const nos_lm_options* options,
                    nos_lm_report* report) {
+  nosd::CtxGuard guard_(ds ? ds->ctx : nullptr);  // one solve / accumulate / create at a time per context
   Request rq;
   int rc = build_request(3, ds, R2, 4, t2, 2, nullptr, 0.0, loss, &rq);
   if (rc != NOS_OK) return rc;
@@ -1498,6 +1643,7 @@ int nos_ndt3_solve(nos_dataset* ds, double R2[4], double t2[2], const nos_loss* 
 
 int nos_reproj_solve(nos_dataset* ds, double R[9], double t[3], const double intr[4], const nos_loss* loss,
                      double min_depth, const nos_lm_options* options, nos_lm_report* report) {
+  nosd::CtxGuard guard_(ds ? ds->ctx : nullptr);  // one solve / accumulate / create at a time per context
   Request rq;
   int rc = build_request(2, ds, R, 9, t, 3, intr, min_depth, loss, &rq);
   if (rc != NOS_OK) return rc;
@@ -1506,6 +1652,7 @@ int nos_reproj_solve(nos_dataset* ds, double R[9], double t[3], const double int
 
 int nos_ndt6_time_kernel(nos_dataset* ds, const double R[9], const double t[3], const nos_loss* loss, int repeats,
                          double* kernel_ms, double* total_ms) {
+  nosd::CtxGuard guard_(ds ? ds->ctx : nullptr);  // one solve / accumulate / create at a time per context
   Request rq;
   int rc = build_request(6, ds, R, 9, t, 3, nullptr, 0.0, loss, &rq);
   if (rc != NOS_OK) return rc;
@@ -1514,6 +1661,7 @@ int nos_ndt6_time_kernel(nos_dataset* ds, const double R[9], const double t[3], 
 
 int nos_ndt3_time_kernel(nos_dataset* ds, const double R2[4], const double t2[2], const nos_loss* loss, int repeats,
                          double* kernel_ms, double* total_ms) {
+  nosd::CtxGuard guard_(ds ? ds->ctx : nullptr);  // one solve / accumulate / create at a time per context
   Request rq;
   int rc = build_request(3, ds, R2, 4, t2, 2, nullptr, 0.0, loss, &rq);
   if (rc != NOS_OK) return rc;
@@ -1523,6 +1671,7 @@ int nos_ndt3_time_kernel(nos_dataset* ds, const double R2[4], const double t2[2]
 int nos_reproj_time_kernel(nos_dataset* ds, const double R[9], const double t[3], const double intr[4],
                            const nos_loss* loss, double min_depth, int repeats, double* kernel_ms,
                            double* total_ms) {
+  nosd::CtxGuard guard_(ds ? ds->ctx : nullptr);  // one solve / accumulate / create at a time per context
   Request rq;
   int rc = build_request(2, ds, R, 9, t, 3, intr, min_depth, loss, &rq);
   if (rc != NOS_OK) return rc;
@@ -1541,6 +1690,7 @@ int nos_comm_get_unique_id(unsigned char id[NOS_COMM_ID_BYTES]) {
 }
 
 int nos_ctx_comm_init(nos_ctx* ctx, int n_ranks, int rank, const unsigned char id[NOS_COMM_ID_BYTES]) {
+  nosd::CtxGuard guard_(ctx);  // one solve / accumulate / create at a time per context
   if (!ctx || !id || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(NOS_ERR_INVALID_ARGUMENT, "bad comm arguments");
   if (ctx->slots.size() != 1) return fail(NOS_ERR_UNSUPPORTED, "a communicator needs a single-device context");
   if (ctx->comm != nullptr) return fail(NOS_ERR_INVALID_ARGUMENT, "communicator already initialised");
@@ -1559,25 +1709,105 @@ int nos_ctx_comm_init(nos_ctx* ctx, int n_ranks, int rank, const unsigned char i
 int nos_ctx_comm_size(const nos_ctx* ctx) { return (ctx && (ctx->comm || ctx->shm_dev)) ? ctx->comm_ranks : 0; }
 
 int nos_ctx_comm_init_shm(nos_ctx* ctx, int n_ranks, int rank, const char* shm_name) {
+  nosd::CtxGuard guard_(ctx);  // one solve / accumulate / create at a time per context
   if (!ctx || !shm_name || shm_name[0] != '/' || n_ranks < 1 || n_ranks > 64 || rank < 0 || rank >= n_ranks)
     return fail(NOS_ERR_INVALID_ARGUMENT, "bad comm arguments (name must start with '/', at most 64 ranks)");
   if (ctx->slots.size() != 1) return fail(NOS_ERR_UNSUPPORTED, "a communicator needs a single-device context");
   if (ctx->comm != nullptr || ctx->shm_dev != nullptr) return fail(NOS_ERR_INVALID_ARGUMENT, "communicator already initialised");
   DeviceSlot& slot = ctx->slots[0];
   NOS_HIP_CHECK(hipSetDevice(slot.device));
-  size_t bytes = size_t(n_ranks) * 2 * nos::kMailSlotDoubles * sizeof(double);
-  bytes = (bytes + 4095) & ~size_t(4095);
-  const int fd = shm_open(shm_name, O_CREAT | O_RDWR, 0600);
-  if (fd < 0) return fail(NOS_ERR_HIP, "shm_open(%s) failed: %s", shm_name, strerror(errno));
-  // every rank sizes the segment (idempotent); pages of a fresh segment read as zero = round 0 everywhere
-  if (ftruncate(fd, off_t(bytes)) != 0) {
-    const int e = errno;
+  size_t bytes = 0;
+  // Attach with a handshake that cannot be fooled by a segment of that name left behind by a crashed run (whose flag
+  // words would otherwise match the first round numbers and feed stale sums into the exchange):
+  //   rank 0 unlinks the name, creates the segment EXCLUSIVELY (a fresh, zero-filled inode), publishes a random nonce and
+  //   acknowledges every rank's own fresh random hello word with hello ^ nonce;
+  //   rank k opens the name (retrying), writes its hello and accepts the mapping only when its acknowledgement shows up —
+  //   a stale inode never acknowledges a fresh 64-bit random, so rank k drops it and opens the name again.
+  // Bounded: NOS_SHM_ATTACH_TIMEOUT_MS (default 30 s) in total.  Header (after the slots): [0] nonce, [1..64] hello, [65..128] ack.
+  const int kAttachTimeoutMs = std::max(100, env_int("NOS_SHM_ATTACH_TIMEOUT_MS", 30000));  // set-up path, not the solve path
+  const size_t slots_bytes = size_t(n_ranks) * 2 * nos::kMailSlotDoubles * sizeof(double);
+  const size_t header_words = 1 + 64 + 64;
+  bytes = (slots_bytes + header_words * sizeof(unsigned long long) + 4095) & ~size_t(4095);
+  auto now_ms = [] {
+    return std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  };
+  auto fresh_random = [&]() -> unsigned long long {
+    unsigned long long v = 0;
+    std::random_device rd;
+    while (v == 0) v = (static_cast<unsigned long long>(rd()) << 32) ^ rd() ^ (static_cast<unsigned long long>(getpid()) << 17);
+    return v;
+  };
+  const long long deadline = now_ms() + kAttachTimeoutMs;
+  void* host = MAP_FAILED;
+  if (rank == 0) {
+    (void)shm_unlink(shm_name);
+    int fd = shm_open(shm_name, O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd < 0 && errno == EEXIST) {  // somebody re-created it in between: once more
+      (void)shm_unlink(shm_name);
+      fd = shm_open(shm_name, O_CREAT | O_EXCL | O_RDWR, 0600);
+    }
+    if (fd < 0) return fail(NOS_ERR_HIP, "shm_open(%s) failed: %s", shm_name, strerror(errno));
+    if (ftruncate(fd, off_t(bytes)) != 0) {  // fresh pages read as zero = round 0 everywhere
+      const int e = errno;
+      close(fd);
+      (void)shm_unlink(shm_name);
+      return fail(NOS_ERR_HIP, "ftruncate(%s) failed: %s", shm_name, strerror(e));
+    }
+    host = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
     close(fd);
-    return fail(NOS_ERR_HIP, "ftruncate(%s) failed: %s", shm_name, strerror(e));
+    if (host == MAP_FAILED) return fail(NOS_ERR_HIP, "mmap(%s) failed: %s", shm_name, strerror(errno));
+    auto* hdr = reinterpret_cast<std::atomic<unsigned long long>*>(static_cast<char*>(host) + slots_bytes);
+    const unsigned long long nonce = fresh_random();
+    hdr[0].store(nonce, std::memory_order_release);
+    for (int k = 1; k < n_ranks; ++k) {
+      unsigned long long hello = 0;
+      while ((hello = hdr[1 + k].load(std::memory_order_acquire)) == 0) {
+        if (now_ms() > deadline) {
+          munmap(host, bytes);
+          return fail(NOS_ERR_HIP, "rank %d did not attach to the mailbox %s within %d ms", k, shm_name, kAttachTimeoutMs);
+        }
+        usleep(200);
+      }
+      hdr[65 + k].store(hello ^ nonce, std::memory_order_release);
+    }
+  } else {
+    const unsigned long long hello = fresh_random();
+    for (;;) {
+      if (now_ms() > deadline)
+        return fail(NOS_ERR_HIP, "mailbox %s: no acknowledgement from rank 0 within %d ms", shm_name, kAttachTimeoutMs);
+      const int fd = shm_open(shm_name, O_RDWR, 0600);
+      if (fd < 0) {
+        usleep(500);
+        continue;
+      }
+      struct stat st {};
+      if (fstat(fd, &st) != 0 || size_t(st.st_size) < bytes) {  // not sized yet (or somebody else's segment)
+        close(fd);
+        usleep(500);
+        continue;
+      }
+      void* m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+      close(fd);
+      if (m == MAP_FAILED) return fail(NOS_ERR_HIP, "mmap(%s) failed: %s", shm_name, strerror(errno));
+      auto* hdr = reinterpret_cast<std::atomic<unsigned long long>*>(static_cast<char*>(m) + slots_bytes);
+      hdr[1 + rank].store(hello, std::memory_order_release);
+      bool acked = false;
+      const long long until = std::min<long long>(deadline, now_ms() + 250);  // then look at the name again
+      while (now_ms() <= until) {
+        const unsigned long long nonce = hdr[0].load(std::memory_order_acquire);
+        if (nonce != 0 && hdr[65 + rank].load(std::memory_order_acquire) == (hello ^ nonce)) {
+          acked = true;
+          break;
+        }
+        usleep(200);
+      }
+      if (acked) {
+        host = m;
+        break;
+      }
+      munmap(m, bytes);  // stale inode (or rank 0 not there yet): drop it and open the name again
+    }
   }
-  void* host = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-  close(fd);
-  if (host == MAP_FAILED) return fail(NOS_ERR_HIP, "mmap(%s) failed: %s", shm_name, strerror(errno));
   hipError_t e = hipHostRegister(host, bytes, hipHostRegisterMapped | hipHostRegisterPortable);
   void* dev = nullptr;
   if (e == hipSuccess) {
@@ -1619,6 +1849,7 @@ int nos_comm_shm_unlink(const char* shm_name) {
 }
 
 int nos_ctx_comm_allreduce(nos_ctx* ctx, double* values, int count) {
+  nosd::CtxGuard guard_(ctx);  // one solve / accumulate / create at a time per context
   if (!ctx || !values || count < 1 || count > kMaxOut) return fail(NOS_ERR_INVALID_ARGUMENT, "bad allreduce arguments");
   if (ctx->comm == nullptr && ctx->shm_dev == nullptr) return fail(NOS_ERR_INVALID_ARGUMENT, "no communicator");
   DeviceSlot& slot = ctx->slots[0];
@@ -1636,6 +1867,7 @@ int nos_ctx_comm_allreduce(nos_ctx* ctx, double* values, int count) {
 }
 
 int nos_ctx_profile_begin(nos_ctx* ctx, int max_launches, int sample_every) {
+  nosd::CtxGuard guard_(ctx);  // one solve / accumulate / create at a time per context
   if (!ctx || max_launches < 1 || max_launches > (1 << 20) || sample_every < 0)
     return fail(NOS_ERR_INVALID_ARGUMENT, "bad profile request");
   for (DeviceSlot& s : ctx->slots) {
@@ -1662,6 +1894,7 @@ int nos_ctx_profile_begin(nos_ctx* ctx, int max_launches, int sample_every) {
 }
 
 int nos_ctx_profile_end(nos_ctx* ctx, int* n_launches, double* mean_ms, double* min_ms, double* max_ms) {
+  nosd::CtxGuard guard_(ctx);  // one solve / accumulate / create at a time per context
   if (!ctx) return fail(NOS_ERR_INVALID_ARGUMENT, "ctx is NULL");
   int count = 0;
   double sum = 0.0, lo = 1e300, hi = 0.0;

@@ -19,7 +19,7 @@ int launch_indexed_kernel(const nos::IndexedLayout& L, const typename Problem::P
   int grid = int(std::min<uint64_t>(std::max<uint64_t>(n_chunks64, 1), uint64_t(grid_cap)));
   if (grid > kMaxPartialRows) grid = kMaxPartialRows;
   nos::FusedFinal fin = fin_in;
-  fin.write_through = (fin.counter != nullptr && grid <= num_cus && env_int("NOS_SC1", 1) != 0) ? 1 : 0;
+  fin.write_through = (fin.counter != nullptr && grid <= num_cus && fin_in.write_through != 0) ? 1 : 0;  // in: allowed
   hipLaunchKernelGGL((nos::assemble_indexed_kernel<Problem, T, K, kBlock, kMinWaves>), dim3(grid), dim3(kBlock), 0, stream, L,
                      P, uint32_t(n_chunks64), partials, fin);
   hipError_t e = hipGetLastError();
@@ -56,7 +56,7 @@ int nosd::launch_indexed(const nos_dataset* ds, const Shard& sh, const Request& 
   L.index = sh.index;
   L.table = sh.table;
   L.n_padded = sh.layout.n_padded;
-  const int bpc = env_int("NOS_INDEXED_BPC", 1);
+  const int bpc = ctx->settings.indexed_bpc;
   const int cap = bpc * slot.num_cus;
   if (rq.problem == 6) {
     if (ds->dtype == NOS_F64) {
@@ -220,6 +220,7 @@ extern "C" {
 int nos_ndt_indexed_dataset_create(nos_ctx* ctx, size_t n_points, const double* const point_planes[3], int n_slots,
                                    const int32_t* const index_planes[], size_t n_voxels, const double* means_xyz,
                                    const double* sqrt_infos, int dtype, int sort_by_voxel, nos_dataset** out_ds) {
+  nosd::CtxGuard guard_(ctx);  // one solve / accumulate / create at a time per context
   if (!ctx || !out_ds) return fail(NOS_ERR_INVALID_ARGUMENT, "ctx / out_ds is NULL");
   *out_ds = nullptr;
   if (ctx->slots.size() != 1) return fail(NOS_ERR_UNSUPPORTED, "voxel-indexed datasets need a single-device context");
@@ -254,6 +255,7 @@ int nos_ndt_indexed_dataset_create(nos_ctx* ctx, size_t n_points, const double* 
 
 int nos_ndt_match_indexed(nos_ndt_map* map, nos_scan* scan, const double R[9], const double t[3], int max_neighbors,
                           int dtype, int sort_by_voxel, nos_dataset** out_ds, size_t* n_matches) {
+  nosd::CtxGuard guard_(map ? map->ctx : nullptr);  // one solve / accumulate / create at a time per context
   if (!map || !scan || !R || !t || !out_ds) return fail(NOS_ERR_INVALID_ARGUMENT, "NULL argument");
   *out_ds = nullptr;
   if (map->ctx != scan->ctx) return fail(NOS_ERR_INVALID_ARGUMENT, "map and scan belong to different contexts");

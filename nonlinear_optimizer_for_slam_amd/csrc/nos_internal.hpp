@@ -5,11 +5,14 @@
 #include <dlfcn.h>
 #include <fcntl.h>
 #include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <rccl/rccl.h>
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <random>
 #include <climits>
 #include <cmath>
 #include <cstdarg>
@@ -21,6 +24,7 @@
 #include <new>
 #include <string>
 #include <thread>
+#include <mutex>
 #include <vector>
 
 #include "../../include/nos.h"
@@ -49,6 +53,9 @@ struct RcclApi {
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*GetVersion)(int*) = nullptr;
+  std::string path;  // file the library was loaded from
   bool ok = false;
 };
 
@@ -106,6 +113,7 @@ struct DeviceSlot {
   };
   std::vector<PoolEntry> pool;
   size_t pool_bytes = 0;
+  bool pool_enabled = true;  // Settings::pool
   std::vector<hipEvent_t> prof_events;
   size_t prof_used = 0;
   bool prof_on = false;
@@ -116,7 +124,33 @@ struct DeviceSlot {
 
 }  // namespace nosd
 
+namespace nosd {
+// Experiment / test knobs.  Read from the environment ONCE, when the context is created (nos_ctx_create), and
+// changed afterwards only through nos_ctx_set_option: nothing on the solve / accumulate path calls getenv().
+struct Settings {
+  int plane_skew = 1088;     // NOS_PLANE_SKEW      elements between consecutive planes beyond n_padded
+  int sc1 = 1;               // NOS_SC1             write-through rows instead of release / acquire fences
+  int nt = -1;               // NOS_NT              -1 auto, 0 / 1 force non-temporal loads off / on
+  int fused = 1;             // NOS_FUSED           in-launch final reduce
+  int lm_fused = 1;          // NOS_LM_FUSED        LM step in the finishing workgroup
+  int lm_window = 3;         // NOS_LM_WINDOW       launches kept in flight by the device loop
+  int lm_single = 1;         // NOS_LM_SINGLE       whole solve in one workgroup for tiny problems
+  int lm_cluster = 1;        // NOS_LM_CLUSTER      whole solve in one launch, data resident on chip
+  int pool = 1;              // NOS_POOL            device-buffer pool
+  int tile_log2 = 0;         // NOS_TILE_LOG2       0 = planar
+  int ingest = 0;            // NOS_INGEST          0 auto, 1 pack (host gather), 2 unpack (device)
+  int ingest_threads = 0;    // NOS_INGEST_THREADS  0 = min(16, hw / 2)
+  int indexed_bpc = 1;       // NOS_INDEXED_BPC
+  int match_dense = 1;       // NOS_MATCH_DENSE
+  int pgo_host_scalars = 0;  // NOS_PGO_HOST_SCALARS
+  int pgo_precond = 1;       // NOS_PGO_PRECOND     0 block-Jacobi only, 1 + chain / coarse correction
+  int debug_cluster_abort = 0;  // test hook (no environment name): the next one-launch solve finds `abort` raised
+};
+}  // namespace nosd
+
 struct nos_ctx {
+  std::recursive_mutex mu;  // serialises every entry point that touches per-context state (see nosd::CtxGuard)
+  nosd::Settings settings;
   std::vector<nosd::DeviceSlot> slots;
   int blocks_per_cu = 0;  // 0 = default
   int variant = 0;        // 0 = default; tuning knob (see pick_variant)
@@ -133,6 +167,18 @@ struct nos_ctx {
 };
 
 namespace nosd {
+
+// One solve / accumulate / dataset create / destroy at a time per context: the per-slot state (sequence words,
+// partial rows, tickets, loop state, pinned result block, staging buffers, buffer pool) is shared by every object
+// created on the context — e.g. by every drop-in solver object with the same device list (AcquireRuntime).  The
+// reference's solver objects are independent per instance; this lock gives the same guarantee to threads that each own
+// their solver.  Recursive: entry points call each other (match → dataset create).
+struct CtxGuard {
+  std::unique_lock<std::recursive_mutex> lock;
+  explicit CtxGuard(const nos_ctx* ctx) {
+    if (ctx != nullptr) lock = std::unique_lock<std::recursive_mutex>(const_cast<nos_ctx*>(ctx)->mu);
+  }
+};
 
 struct Shard {
   int slot = 0;

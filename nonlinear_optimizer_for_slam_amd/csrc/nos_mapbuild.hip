@@ -23,6 +23,7 @@ extern "C" {
 // per scan (not per outer iteration).  The order of the matcher's output slots follows the new point order;
 // nos_scan_order returns the permutation.
 int nos_scan_sort_by_cell(nos_scan* scan, double cell_edge) {
+  nosd::CtxGuard guard_(scan ? scan->ctx : nullptr);  // one solve / accumulate / create at a time per context
   if (!scan) return fail(NOS_ERR_INVALID_ARGUMENT, "scan is NULL");
   if (!(cell_edge > 0.0) || !std::isfinite(cell_edge)) return fail(NOS_ERR_INVALID_ARGUMENT, "bad cell edge");
   const size_t n = scan->n;
@@ -82,6 +83,7 @@ int nos_scan_sort_by_cell(nos_scan* scan, double cell_edge) {
 }
 
 int nos_scan_order(const nos_scan* scan, uint32_t* order_out) {
+  nosd::CtxGuard guard_(scan ? scan->ctx : nullptr);  // one solve / accumulate / create at a time per context
   if (!scan || (!order_out && scan->n > 0)) return fail(NOS_ERR_INVALID_ARGUMENT, "NULL argument");
   if (scan->d_order == nullptr) {
     for (size_t i = 0; i < scan->n; ++i) order_out[i] = uint32_t(i);
@@ -114,6 +116,7 @@ int nos_map_stats_get(const nos_map_stats* stats, double* means_xyz, double* sqr
 
 int nos_ndt_map_build(nos_ctx* ctx, size_t n_points, const double* points_xyz, double voxel_resolution,
                       double search_radius_sq, int flags, nos_ndt_map** out_map, nos_map_stats** out_stats) {
+  nosd::CtxGuard guard_(ctx);  // one solve / accumulate / create at a time per context
   if (!ctx || !out_map) return fail(NOS_ERR_INVALID_ARGUMENT, "ctx / out_map is NULL");
   *out_map = nullptr;
   if (out_stats) *out_stats = nullptr;

@@ -7,6 +7,7 @@ extern "C" {
 
 int nos_ndt_map_create(nos_ctx* ctx, size_t n_voxels, const double* means_xyz, const double* sqrt_infos,
                        const unsigned char* valid, double search_radius_sq, nos_ndt_map** out_map) {
+  nosd::CtxGuard guard_(ctx);  // one solve / accumulate / create at a time per context
   if (!ctx || !out_map) return fail(NOS_ERR_INVALID_ARGUMENT, "ctx / out_map is NULL");
   *out_map = nullptr;
   if (ctx->slots.size() != 1) return fail(NOS_ERR_UNSUPPORTED, "the matcher needs a single-device context");
@@ -68,7 +69,7 @@ int nos_ndt_map_create(nos_ctx* ctx, size_t n_voxels, const double* means_xyz, c
   std::vector<uint32_t> dense_begin;
   std::vector<double> records;
   int64_t lo[3] = {0, 0, 0}, dim[3] = {0, 0, 0};
-  if (!cells.empty() && env_int("NOS_MATCH_DENSE", 1) != 0) {
+  if (!cells.empty() && ctx->settings.match_dense != 0) {
     const int64_t bias = int64_t(1) << 20;
     int64_t mn[3] = {INT64_MAX, INT64_MAX, INT64_MAX}, mx[3] = {INT64_MIN, INT64_MIN, INT64_MIN};
     auto unpack = [&](uint64_t key, int64_t c[3]) {
@@ -151,6 +152,7 @@ int nos_ndt_map_create(nos_ctx* ctx, size_t n_voxels, const double* means_xyz, c
 }
 
 int nos_ndt_map_destroy(nos_ndt_map* map) {
+  nosd::CtxGuard guard_(map ? map->ctx : nullptr);  // one solve / accumulate / create at a time per context
   if (!map) return NOS_OK;
   (void)hipSetDevice(map->ctx->slots[0].device);
   if (map->d_mean) (void)hipFree(map->d_mean);
@@ -169,6 +171,7 @@ int nos_ndt_map_destroy(nos_ndt_map* map) {
 size_t nos_ndt_map_size(const nos_ndt_map* map) { return map ? map->n_voxels : 0; }
 
 int nos_scan_create(nos_ctx* ctx, size_t n_points, const double* points_xyz, nos_scan** out_scan) {
+  nosd::CtxGuard guard_(ctx);  // one solve / accumulate / create at a time per context
   if (!ctx || !out_scan) return fail(NOS_ERR_INVALID_ARGUMENT, "ctx / out_scan is NULL");
   *out_scan = nullptr;
   if (ctx->slots.size() != 1) return fail(NOS_ERR_UNSUPPORTED, "the matcher needs a single-device context");
@@ -213,6 +216,7 @@ int nos_scan_create(nos_ctx* ctx, size_t n_points, const double* points_xyz, nos
 }
 
 int nos_scan_destroy(nos_scan* scan) {
+  nosd::CtxGuard guard_(scan ? scan->ctx : nullptr);  // one solve / accumulate / create at a time per context
   if (!scan) return NOS_OK;
   (void)hipSetDevice(scan->ctx->slots[0].device);
   if (scan->d_planes) (void)hipFree(scan->d_planes);
@@ -225,6 +229,7 @@ size_t nos_scan_size(const nos_scan* scan) { return scan ? scan->n : 0; }
 
 int nos_ndt_match(nos_ndt_map* map, nos_scan* scan, const double R[9], const double t[3], int max_neighbors,
                   int dtype, nos_dataset** out_ds, size_t* n_matches) {
+  nosd::CtxGuard guard_(map ? map->ctx : nullptr);  // one solve / accumulate / create at a time per context
   if (!map || !scan || !R || !t || !out_ds) return fail(NOS_ERR_INVALID_ARGUMENT, "NULL argument");
   if (map->ctx != scan->ctx) return fail(NOS_ERR_INVALID_ARGUMENT, "map and scan belong to different contexts");
   if (max_neighbors < 1 || max_neighbors > 2) return fail(NOS_ERR_UNSUPPORTED, "max_neighbors must be 1 or 2");
@@ -271,6 +276,7 @@ int nos_ndt_match(nos_ndt_map* map, nos_scan* scan, const double R[9], const dou
 }
 
 int nos_dataset_download(nos_dataset* ds, double* const planes[]) {
+  nosd::CtxGuard guard_(ds ? ds->ctx : nullptr);  // one solve / accumulate / create at a time per context
   if (!ds || !planes) return fail(NOS_ERR_INVALID_ARGUMENT, "NULL argument");
   size_t begin = 0;
   for (const Shard& sh : ds->shards) {

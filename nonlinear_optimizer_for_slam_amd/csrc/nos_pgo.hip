@@ -77,6 +77,7 @@ int pgo_matvec(nos_pose_graph* pg, double lambda, const double* x, double* y, do
 extern "C" {
 
 int nos_pgo_destroy(nos_pose_graph* pg) {
+  nosd::CtxGuard guard_(pg ? pg->ctx : nullptr);  // one solve / accumulate / create at a time per context
   if (!pg) return NOS_OK;
   void* bufs[] = {pg->d_pose, pg->d_ref, pg->d_qry, pg->d_edge, pg->d_adj_nbr, pg->d_sw_free, pg->d_fixed, pg->d_adj_off,
                   pg->d_adj, pg->d_hdiag, pg->d_minv, pg->d_hs, pg->d_grad, pg->d_x, pg->d_r, pg->d_z, pg->d_p,
@@ -94,6 +95,7 @@ int nos_pgo_destroy(nos_pose_graph* pg) {
 int nos_pgo_create(nos_ctx* ctx, size_t n_poses, const double* poses, size_t n_edges, const int32_t* ref,
                    const int32_t* qry, const double* meas, const double* switch_init,
                    const unsigned char* switch_free, const unsigned char* fixed, nos_pose_graph** out_pg) {
+  nosd::CtxGuard guard_(ctx);  // one solve / accumulate / create at a time per context
   if (!ctx || !out_pg) return fail(NOS_ERR_INVALID_ARGUMENT, "ctx / out_pg is NULL");
   *out_pg = nullptr;
   if (ctx->slots.size() != 1) return fail(NOS_ERR_UNSUPPORTED, "pose-graph optimisation needs a single-device context");
@@ -197,6 +199,7 @@ size_t nos_pgo_num_unknowns(const nos_pose_graph* pg) { return pg ? pg->n_unknow
 // Linearise at the current estimate: diagonal blocks, gradient, cost = sum of squared residuals,
 // |gradient|_2.  Must precede nos_pgo_solve / nos_pgo_matvec.
 int nos_pgo_linearize(nos_pose_graph* pg, double* cost, double* gradient_norm) {
+  nosd::CtxGuard guard_(pg ? pg->ctx : nullptr);  // one solve / accumulate / create at a time per context
   if (!pg) return fail(NOS_ERR_INVALID_ARGUMENT, "pg is NULL");
   DeviceSlot& slot = pg->ctx->slots[0];
   NOS_HIP_CHECK(hipSetDevice(slot.device));
@@ -223,6 +226,7 @@ int nos_pgo_linearize(nos_pose_graph* pg, double* cost, double* gradient_norm) {
 // Stops at |residual| <= rel_tolerance |gradient| or after max_iterations.
 int nos_pgo_solve(nos_pose_graph* pg, double lambda, int max_iterations, double rel_tolerance, int* iterations,
                   double* rel_residual, double* step_norm) {
+  nosd::CtxGuard guard_(pg ? pg->ctx : nullptr);  // one solve / accumulate / create at a time per context
   if (!pg) return fail(NOS_ERR_INVALID_ARGUMENT, "pg is NULL");
   DeviceSlot& slot = pg->ctx->slots[0];
   NOS_HIP_CHECK(hipSetDevice(slot.device));
@@ -258,7 +262,7 @@ int nos_pgo_solve(nos_pose_graph* pg, double lambda, int max_iterations, double 
   NOS_HIP_CHECK(hipMemcpyAsync(pg->d_p, pg->d_z, n * sizeof(double), hipMemcpyDeviceToDevice, slot.stream));
   int it = 0;
   double res = b_norm;
-  if (b_norm > 0.0 && env_int("NOS_PGO_HOST_SCALARS", 0) == 0) {
+  if (b_norm > 0.0 && pg->ctx->settings.pgo_host_scalars == 0) {
     // CG scalars stay on the device (pgo_cg_alpha / beta kernels); the host looks at |r| only every kCheck iterations,
     // so up to kCheck - 1 iterations more than strictly needed may run (they only improve the step).
     constexpr int kCheck = 8;
@@ -329,6 +333,7 @@ int nos_pgo_solve(nos_pose_graph* pg, double lambda, int max_iterations, double 
 
 // Apply the last computed step: p += dp, q = normalize(q (x) Exp(dw)), s += ds.
 int nos_pgo_retract(nos_pose_graph* pg) {
+  nosd::CtxGuard guard_(pg ? pg->ctx : nullptr);  // one solve / accumulate / create at a time per context
   if (!pg) return fail(NOS_ERR_INVALID_ARGUMENT, "pg is NULL");
   DeviceSlot& slot = pg->ctx->slots[0];
   NOS_HIP_CHECK(hipSetDevice(slot.device));
@@ -341,6 +346,7 @@ int nos_pgo_retract(nos_pose_graph* pg) {
 }
 
 int nos_pgo_get_state(nos_pose_graph* pg, double* poses, double* switches) {
+  nosd::CtxGuard guard_(pg ? pg->ctx : nullptr);  // one solve / accumulate / create at a time per context
   if (!pg) return fail(NOS_ERR_INVALID_ARGUMENT, "pg is NULL");
   const uint32_t N = pg->n_poses, M = pg->n_edges;
   NOS_HIP_CHECK(hipSetDevice(pg->ctx->slots[0].device));
@@ -361,6 +367,7 @@ int nos_pgo_get_state(nos_pose_graph* pg, double* poses, double* switches) {
 
 // Diagnostics for the parity tests: which = 0 gradient, 1 last step, 2 diagonal blocks (21 planes).
 int nos_pgo_get_vector(nos_pose_graph* pg, int which, double* out) {
+  nosd::CtxGuard guard_(pg ? pg->ctx : nullptr);  // one solve / accumulate / create at a time per context
   if (!pg || !out) return fail(NOS_ERR_INVALID_ARGUMENT, "NULL argument");
   NOS_HIP_CHECK(hipSetDevice(pg->ctx->slots[0].device));
   NOS_HIP_CHECK(hipStreamSynchronize(pg->ctx->slots[0].stream));
@@ -381,6 +388,7 @@ int nos_pgo_get_vector(nos_pose_graph* pg, int which, double* out) {
 
 // y = (H with damped diagonal) x for a host vector (tests).
 int nos_pgo_matvec(nos_pose_graph* pg, double lambda, const double* x, double* y) {
+  nosd::CtxGuard guard_(pg ? pg->ctx : nullptr);  // one solve / accumulate / create at a time per context
   if (!pg || !x || !y) return fail(NOS_ERR_INVALID_ARGUMENT, "NULL argument");
   DeviceSlot& slot = pg->ctx->slots[0];
   NOS_HIP_CHECK(hipSetDevice(slot.device));

@@ -41,7 +41,7 @@ def build(force=False):
     """Compile the oracle libraries with the committed Makefile (gcc only)."""
     need = force or not all(
         os.path.exists(os.path.join(_BUILD, f))
-        for f in ("libnos_oracle.so", "libnos_oracle_avx.so")
+        for f in ("libnos_oracle.so", "libnos_oracle_avx.so", "libnos_scene_oracle.so")
     )
     if need:
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
@@ -232,6 +232,35 @@ def quat_to_matrix(q):
     R = np.zeros(9)
     lib().oracle_quat_to_matrix(q.ctypes.data_as(c_double_p), R.ctypes.data_as(c_double_p))
     return R.reshape(3, 3)
+
+
+def _avx_call(fn_name, planes_f32, count, n_out, vecs, loss, threads):
+    p = np.ascontiguousarray(planes_f32, dtype=np.float32)
+    assert p.ndim == 2 and p.shape[0] == count
+    fp = ctypes.POINTER(ctypes.c_float)
+    arr = (fp * count)()
+    for k in range(count):
+        arr[k] = p[k].ctypes.data_as(fp)
+    out = np.zeros(n_out)
+    l = make_loss(loss)
+    fn = getattr(avx(), fn_name)
+    fn.restype = ctypes.c_int
+    args = [ctypes.c_size_t(p.shape[1]), arr] + [v.ctypes.data_as(c_double_p) for v in vecs]
+    rc = fn(*args, ctypes.byref(l), ctypes.c_int(threads), out.ctypes.data_as(c_double_p))
+    if rc != 0:
+        raise RuntimeError("%s failed: %d" % (fn_name, rc))
+    return out
+
+
+def avx_ndt3_accumulate(planes_f32, R2, t2, loss=None, threads=1):
+    """AVX2/FMA fp32 restatement of MDM/..._analytic_3dof_simd.cc:85-158 (floor(n/8)*8 items)."""
+    return _avx_call("oracle_avx_ndt3_accumulate", planes_f32, 15, 10, [_vec(R2, 4), _vec(t2, 2)], loss, threads)
+
+
+def avx_reproj_accumulate(planes_f32, R, t, intr, loss=None, threads=1):
+    """AVX2/FMA fp32 restatement of REM/..._analytic_simd.cc:55-138; intr = {inv_fx, inv_fy, cx, cy}."""
+    return _avx_call("oracle_avx_reproj_accumulate", planes_f32, 5, 28, [_vec(R, 9), _vec(t, 3), _vec(intr, 4)], loss,
+                     threads)
 
 
 def avx_ndt6_accumulate(planes_f32, R, t, loss=None, threads=1):

@@ -10,6 +10,13 @@
  * caller sums the partials in thread order (MDM/..._analytic_simd.cc:55-76).
  * Used only as the "repo's own AVX path" timing baseline beside the GPU numbers and as
  * a coarse fp32 cross-check of the scalar oracle.
+ *
+ * The same treatment for the two other SIMD classes of the reference (both single-threaded there: neither has
+ * a SetMultiThreadExecutor path; the thread fan-out offered here reuses the 6-DoF partition and is an
+ * extrapolation, stated as such wherever it is reported):
+ *   oracle_avx_ndt3_accumulate    MDM/mahalanobis_distance_minimizer_analytic_3dof_simd.cc:85-158 (+ lane sums :160-177)
+ *   oracle_avx_reproj_accumulate  REM/reprojection_error_minimizer_analytic_simd.cc:55-138 (+ lane sums :140-157):
+ *                                 depth mask `Xw.z > 0` multiplying the weight (:66,92), 1/fx evaluated in float (:29-30)
  */
 #include <immintrin.h>
 #include <math.h>
@@ -24,6 +31,8 @@ typedef struct avx_job {
   const float* const* planes;
   size_t begin, end; /* multiples of 8 */
   float R[9], t[3];
+  float intr[4]; /* reprojection: 1/fx, 1/fy, cx, cy (floats, as the SIMD class broadcasts them) */
+  int kind;      /* 0: 6-DoF NDT, 1: 3-DoF NDT, 2: reprojection */
   oracle_loss loss;
   double out28[28];
 } avx_job;
@@ -104,8 +113,146 @@ static void avx_range(avx_job* job) {
   job->out28[27] = (double)hsum8(cost);
 }
 
+
+static inline void lane_loss(const oracle_loss* loss, __m256 s, __m256* rho, __m256* w) {
+  /* per lane through the scalar double virtual, as the reference does (…_3dof_simd.cc:131-141, REM/…_simd.cc:78-91) */
+  float sb[8], lb[8], wb[8];
+  int k;
+  _mm256_storeu_ps(sb, s);
+  for (k = 0; k < 8; ++k) {
+    double lr, lw;
+    oracle_loss_evaluate(loss, (double)sb[k], &lr, &lw);
+    lb[k] = (float)lr;
+    wb[k] = (float)lw;
+  }
+  *rho = _mm256_loadu_ps(lb);
+  *w = _mm256_loadu_ps(wb);
+}
+
+/* MDM/mahalanobis_distance_minimizer_analytic_3dof_simd.cc:85-158; R = {R00 R01 R10 R11}, t = {tx ty}. out: H upper (6), g (3), cost. */
+static void avx_range3(avx_job* job) {
+  __m256 R[4], t[2], H[6], g[3], cost;
+  const float* const* pl = job->planes;
+  size_t i;
+  int a, b, k;
+  for (k = 0; k < 4; ++k) R[k] = _mm256_set1_ps(job->R[k]);
+  for (k = 0; k < 2; ++k) t[k] = _mm256_set1_ps(job->t[k]);
+  for (k = 0; k < 6; ++k) H[k] = _mm256_setzero_ps();
+  for (k = 0; k < 3; ++k) g[k] = _mm256_setzero_ps();
+  cost = _mm256_setzero_ps();
+  for (i = job->begin; i < job->end; i += 8) {
+    __m256 p[3], mu[3], S[9], e[3], r[3], J[9], d0, d1, s, rho, w;
+    for (k = 0; k < 3; ++k) p[k] = _mm256_loadu_ps(pl[k] + i);
+    for (k = 0; k < 3; ++k) mu[k] = _mm256_loadu_ps(pl[3 + k] + i);
+    for (k = 0; k < 9; ++k) S[k] = _mm256_loadu_ps(pl[6 + k] + i);
+    e[0] = _mm256_sub_ps(_mm256_fmadd_ps(R[0], p[0], _mm256_fmadd_ps(R[1], p[1], t[0])), mu[0]);
+    e[1] = _mm256_sub_ps(_mm256_fmadd_ps(R[2], p[0], _mm256_fmadd_ps(R[3], p[1], t[1])), mu[1]);
+    e[2] = _mm256_sub_ps(p[2], mu[2]);
+    for (a = 0; a < 3; ++a)
+      r[a] = _mm256_fmadd_ps(S[3 * a], e[0], _mm256_fmadd_ps(S[3 * a + 1], e[1], _mm256_mul_ps(S[3 * a + 2], e[2])));
+    d0 = _mm256_fmsub_ps(R[1], p[0], _mm256_mul_ps(R[0], p[1]));
+    d1 = _mm256_fmsub_ps(R[3], p[0], _mm256_mul_ps(R[2], p[1]));
+    for (a = 0; a < 3; ++a) {
+      J[3 * a + 0] = S[3 * a + 0];
+      J[3 * a + 1] = S[3 * a + 1];
+      J[3 * a + 2] = _mm256_fmadd_ps(S[3 * a], d0, _mm256_mul_ps(S[3 * a + 1], d1));
+    }
+    s = _mm256_fmadd_ps(r[0], r[0], _mm256_fmadd_ps(r[1], r[1], _mm256_mul_ps(r[2], r[2])));
+    rho = s;
+    w = _mm256_set1_ps(1.0f);
+    if (job->loss.kind != 0) lane_loss(&job->loss, s, &rho, &w);
+    for (a = 0; a < 3; ++a)
+      g[a] = _mm256_add_ps(g[a], _mm256_mul_ps(w, _mm256_fmadd_ps(J[a], r[0], _mm256_fmadd_ps(J[3 + a], r[1],
+                                                                                             _mm256_mul_ps(J[6 + a], r[2])))));
+    k = 0;
+    for (a = 0; a < 3; ++a)
+      for (b = a; b < 3; ++b) {
+        H[k] = _mm256_add_ps(H[k], _mm256_mul_ps(w, _mm256_fmadd_ps(J[a], J[b], _mm256_fmadd_ps(J[3 + a], J[3 + b],
+                                                                                               _mm256_mul_ps(J[6 + a], J[6 + b])))));
+        ++k;
+      }
+    cost = _mm256_add_ps(cost, rho);
+  }
+  memset(job->out28, 0, sizeof(job->out28));
+  for (k = 0; k < 6; ++k) job->out28[k] = (double)hsum8(H[k]);
+  for (k = 0; k < 3; ++k) job->out28[6 + k] = (double)hsum8(g[k]);
+  job->out28[9] = (double)hsum8(cost);
+}
+
+/* REM/reprojection_error_minimizer_analytic_simd.cc:55-138; planes X Y Z px py. */
+static void avx_range_reproj(avx_job* job) {
+  __m256 R[9], t[3], H[21], g[6], cost, inv_fx, inv_fy, cx, cy;
+  const float* const* pl = job->planes;
+  const __m256 one = _mm256_set1_ps(1.0f), zero = _mm256_setzero_ps();
+  size_t i;
+  int a, b, k;
+  for (k = 0; k < 9; ++k) R[k] = _mm256_set1_ps(job->R[k]);
+  for (k = 0; k < 3; ++k) t[k] = _mm256_set1_ps(job->t[k]);
+  inv_fx = _mm256_set1_ps(job->intr[0]);
+  inv_fy = _mm256_set1_ps(job->intr[1]);
+  cx = _mm256_set1_ps(job->intr[2]);
+  cy = _mm256_set1_ps(job->intr[3]);
+  for (k = 0; k < 21; ++k) H[k] = _mm256_setzero_ps();
+  for (k = 0; k < 6; ++k) g[k] = _mm256_setzero_ps();
+  cost = _mm256_setzero_ps();
+  for (i = job->begin; i < job->end; i += 8) {
+    __m256 X[3], px, py, Xw[3], M[9], J[12], r[2], mask, iz, iz2, xz, yz, s, rho, w;
+    for (k = 0; k < 3; ++k) X[k] = _mm256_loadu_ps(pl[k] + i);
+    px = _mm256_loadu_ps(pl[3] + i);
+    py = _mm256_loadu_ps(pl[4] + i);
+    for (a = 0; a < 3; ++a)
+      Xw[a] = _mm256_fmadd_ps(R[3 * a], X[0], _mm256_fmadd_ps(R[3 * a + 1], X[1], _mm256_fmadd_ps(R[3 * a + 2], X[2], t[a])));
+    mask = _mm256_and_ps(_mm256_cmp_ps(Xw[2], zero, _CMP_GT_OQ), one); /* 0/1 mask, :66 */
+    iz = _mm256_div_ps(one, Xw[2]);
+    r[0] = _mm256_fmsub_ps(Xw[0], iz, _mm256_mul_ps(inv_fx, _mm256_sub_ps(px, cx)));
+    r[1] = _mm256_fmsub_ps(Xw[1], iz, _mm256_mul_ps(inv_fy, _mm256_sub_ps(py, cy)));
+    s = _mm256_fmadd_ps(r[0], r[0], _mm256_mul_ps(r[1], r[1]));
+    rho = s;
+    w = one;
+    if (job->loss.kind != 0) lane_loss(&job->loss, s, &rho, &w);
+    w = _mm256_mul_ps(w, mask); /* :92 */
+    for (a = 0; a < 3; ++a) {
+      M[3 * a + 0] = _mm256_fmsub_ps(R[3 * a + 2], X[1], _mm256_mul_ps(R[3 * a + 1], X[2]));
+      M[3 * a + 1] = _mm256_fmsub_ps(R[3 * a + 0], X[2], _mm256_mul_ps(R[3 * a + 2], X[0]));
+      M[3 * a + 2] = _mm256_fmsub_ps(R[3 * a + 1], X[0], _mm256_mul_ps(R[3 * a + 0], X[1]));
+    }
+    iz2 = _mm256_mul_ps(iz, iz);
+    xz = _mm256_mul_ps(Xw[0], iz2);
+    yz = _mm256_mul_ps(Xw[1], iz2);
+    J[0] = iz;
+    J[1] = zero;
+    J[2] = _mm256_sub_ps(zero, xz);
+    J[6] = zero;
+    J[7] = iz;
+    J[8] = _mm256_sub_ps(zero, yz);
+    for (b = 0; b < 3; ++b) {
+      J[3 + b] = _mm256_fmsub_ps(iz, M[b], _mm256_mul_ps(xz, M[6 + b]));
+      J[9 + b] = _mm256_fmsub_ps(iz, M[3 + b], _mm256_mul_ps(yz, M[6 + b]));
+    }
+    for (a = 0; a < 6; ++a)
+      g[a] = _mm256_add_ps(g[a], _mm256_mul_ps(_mm256_fmadd_ps(J[a], r[0], _mm256_mul_ps(J[6 + a], r[1])), w));
+    k = 0;
+    for (a = 0; a < 6; ++a)
+      for (b = a; b < 6; ++b) {
+        H[k] = _mm256_add_ps(H[k], _mm256_mul_ps(_mm256_mul_ps(J[a], J[b]), w));
+        H[k] = _mm256_add_ps(H[k], _mm256_mul_ps(_mm256_mul_ps(J[6 + a], J[6 + b]), w));
+        ++k;
+      }
+    cost = _mm256_add_ps(cost, rho);
+  }
+  for (k = 0; k < 21; ++k) job->out28[k] = (double)hsum8(H[k]);
+  for (k = 0; k < 6; ++k) job->out28[21 + k] = (double)hsum8(g[k]);
+  job->out28[27] = (double)hsum8(cost);
+}
+
 static void* avx_thread(void* arg) {
-  avx_range((avx_job*)arg);
+  avx_job* job = (avx_job*)arg;
+  if (job->kind == 1)
+    avx_range3(job);
+  else if (job->kind == 2)
+    avx_range_reproj(job);
+  else
+    avx_range(job);
   return NULL;
 }
 
@@ -131,13 +278,11 @@ void oracle_loss_evaluate(const oracle_loss* loss, double s, double* rho, double
   }
 }
 
-/* planes: 15 float arrays.  Processes floor(n/8)*8 items split into `threads` contiguous
- * batches of floor(floor(n/8)/threads)*8 (last batch clipped), exactly the reference's
- * partition (MDM/..._analytic_simd.cc:57-69) — so with T threads up to 8*T-8 further tail
- * items are dropped, as in the reference. */
-int oracle_avx_ndt6_accumulate(size_t n, const float* const planes[15], const double R[9],
-                               const double t[3], const oracle_loss* loss, int threads,
-                               double out28[28]) {
+/* Processes floor(n/8)*8 items split into `threads` contiguous batches of floor(floor(n/8)/threads)*8 (last batch
+ * clipped), exactly the reference's partition (MDM/..._analytic_simd.cc:57-69) — so with T threads up to 8*T-8 further
+ * tail items are dropped, as in the reference. */
+static int avx_run(int kind, size_t n, const float* const* planes, const double* R, int nR, const double* t, int nt,
+                   const double* intr, const oracle_loss* loss, int threads, double* out, int n_out) {
   const size_t num_stride = n / 8;
   avx_job* jobs;
   pthread_t* tids;
@@ -156,24 +301,51 @@ int oracle_avx_ndt6_accumulate(size_t n, const float* const planes[15], const do
       size_t b = (size_t)i * num_batch, e = ((size_t)i + 1) * num_batch;
       if (e > num_stride * 8) e = num_stride * 8;
       if (b > e) b = e;
+      jobs[i].kind = kind;
       jobs[i].planes = planes;
       jobs[i].begin = b;
       jobs[i].end = e;
-      for (k = 0; k < 9; ++k) jobs[i].R[k] = (float)R[k];
-      for (k = 0; k < 3; ++k) jobs[i].t[k] = (float)t[k];
+      for (k = 0; k < nR; ++k) jobs[i].R[k] = (float)R[k];
+      for (k = 0; k < nt; ++k) jobs[i].t[k] = (float)t[k];
+      if (intr) {
+        /* the SIMD class broadcasts 1.0f / fx computed in float, and cx, cy cast to float (REM/..._simd.cc:29-32);
+         * intr here = {inv_fx, inv_fy, cx, cy} in double like the C ABI: recover fx as 1/inv_fx first */
+        jobs[i].intr[0] = 1.0f / (float)(1.0 / intr[0]);
+        jobs[i].intr[1] = 1.0f / (float)(1.0 / intr[1]);
+        jobs[i].intr[2] = (float)intr[2];
+        jobs[i].intr[3] = (float)intr[3];
+      }
       if (loss) jobs[i].loss = *loss;
     }
   }
   if (threads == 1) {
-    avx_range(&jobs[0]);
+    avx_thread(&jobs[0]);
   } else {
     for (i = 0; i < threads; ++i) pthread_create(&tids[i], NULL, avx_thread, &jobs[i]);
     for (i = 0; i < threads; ++i) pthread_join(tids[i], NULL);
   }
-  memset(out28, 0, 28 * sizeof(double));
+  memset(out, 0, (size_t)n_out * sizeof(double));
   for (i = 0; i < threads; ++i)
-    for (k = 0; k < 28; ++k) out28[k] += jobs[i].out28[k];
+    for (k = 0; k < n_out; ++k) out[k] += jobs[i].out28[k];
   free(jobs);
   free(tids);
   return 0;
+}
+
+int oracle_avx_ndt6_accumulate(size_t n, const float* const planes[15], const double R[9],
+                               const double t[3], const oracle_loss* loss, int threads,
+                               double out28[28]) {
+  return avx_run(0, n, planes, R, 9, t, 3, NULL, loss, threads, out28, 28);
+}
+
+int oracle_avx_ndt3_accumulate(size_t n, const float* const planes[15], const double R2[4],
+                               const double t2[2], const oracle_loss* loss, int threads,
+                               double out10[10]) {
+  return avx_run(1, n, planes, R2, 4, t2, 2, NULL, loss, threads, out10, 10);
+}
+
+int oracle_avx_reproj_accumulate(size_t n, const float* const planes[5], const double R[9],
+                                 const double t[3], const double intr[4], const oracle_loss* loss,
+                                 int threads, double out28[28]) {
+  return avx_run(2, n, planes, R, 9, t, 3, intr, loss, threads, out28, 28);
 }

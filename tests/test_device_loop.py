@@ -59,23 +59,19 @@ def test_device_loop_is_independent_of_launches_in_flight_and_step_placement(ctx
     ds = NdtDataset.from_planes(ctx, planes, "f64")
     cluster = ds.solve6(np.eye(3), np.zeros(3), EXP, max_iterations=50)   # default at this size: one launch
     assert cluster[2]["launches"] == 1
-    os.environ["NOS_LM_CLUSTER"] = "0"                                    # the rest: one launch per iteration
-    ref = ds.solve6(np.eye(3), np.zeros(3), EXP, max_iterations=50, launches_in_flight=1)
-    assert ref[2]["launches"] > 1 and ref[2]["iterations"] == cluster[2]["iterations"]
-    dt, dq = helpers.pose_delta(cluster[0].reshape(3, 3), cluster[1], ref[0].reshape(3, 3), ref[1])
-    assert dt < 1e-10 and dq < 1e-10, (dt, dq)
-    np.testing.assert_allclose(cluster[2]["cost_history"], ref[2]["cost_history"], rtol=1e-11)
-    for window in (3, 16):
-        got = ds.solve6(np.eye(3), np.zeros(3), EXP, max_iterations=50, launches_in_flight=window)
-        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
-        assert got[2]["iterations"] == ref[2]["iterations"]
-        assert np.array_equal(got[2]["cost_history"], ref[2]["cost_history"])
-    os.environ["NOS_LM_FUSED"] = "0"
-    try:
-        got = ds.solve6(np.eye(3), np.zeros(3), EXP, max_iterations=50)
-    finally:
-        del os.environ["NOS_LM_FUSED"]
-        del os.environ["NOS_LM_CLUSTER"]
+    with ctx.options(lm_cluster=0):                                       # the rest: one launch per iteration
+        ref = ds.solve6(np.eye(3), np.zeros(3), EXP, max_iterations=50, launches_in_flight=1)
+        assert ref[2]["launches"] > 1 and ref[2]["iterations"] == cluster[2]["iterations"]
+        dt, dq = helpers.pose_delta(cluster[0].reshape(3, 3), cluster[1], ref[0].reshape(3, 3), ref[1])
+        assert dt < 1e-10 and dq < 1e-10, (dt, dq)
+        np.testing.assert_allclose(cluster[2]["cost_history"], ref[2]["cost_history"], rtol=1e-11)
+        for window in (3, 16):
+            got = ds.solve6(np.eye(3), np.zeros(3), EXP, max_iterations=50, launches_in_flight=window)
+            assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+            assert got[2]["iterations"] == ref[2]["iterations"]
+            assert np.array_equal(got[2]["cost_history"], ref[2]["cost_history"])
+        with ctx.options(lm_fused=0):
+            got = ds.solve6(np.eye(3), np.zeros(3), EXP, max_iterations=50)
     assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
     assert np.array_equal(got[2]["cost_history"], ref[2]["cost_history"])
     ds.close()
@@ -229,20 +225,16 @@ def test_cpp_classes_use_the_device_loop_by_default_and_agree_with_the_host_loop
 @pytest.mark.parametrize("loss", [EXP, ("huber", 0.7)])
 def test_single_workgroup_solve_equals_the_launch_per_iteration_loop(ctx, oracle, n, loss):
     """Up to 1024 NDT correspondences nos_ndt6_solve runs the whole loop inside one workgroup (one launch).  Same loop body,
-    same data: iterations, costs and pose must match the launch-per-iteration form (NOS_LM_SINGLE=0) to the last bits
+    same data: iterations, costs and pose must match the launch-per-iteration form (context option lm_single = 0) to the last bits
     that the different summation order allows, and the oracle's loop."""
     planes = synth.ndt_planes(n, max(1, n // 30))
     ds = NdtDataset.from_planes(ctx, planes, "f64")
     one = ds.solve6(np.eye(3), np.zeros(3), loss, max_iterations=60)
     assert one[2]["launches"] == 1
-    os.environ["NOS_LM_SINGLE"] = "0"
-    try:
+    with ctx.options(lm_single=0):
         cluster = ds.solve6(np.eye(3), np.zeros(3), loss, max_iterations=60)   # chunk-per-workgroup form, one launch
-        os.environ["NOS_LM_CLUSTER"] = "0"
-        many = ds.solve6(np.eye(3), np.zeros(3), loss, max_iterations=60)      # one launch per iteration
-    finally:
-        del os.environ["NOS_LM_SINGLE"]
-        os.environ.pop("NOS_LM_CLUSTER", None)
+        with ctx.options(lm_cluster=0):
+            many = ds.solve6(np.eye(3), np.zeros(3), loss, max_iterations=60)  # one launch per iteration
     assert cluster[2]["launches"] == 1 and cluster[2]["iterations"] == many[2]["iterations"]
     assert cluster[2]["ok"] == many[2]["ok"]
     if cluster[2]["ok"]:
@@ -411,17 +403,14 @@ def test_cluster_solve_falls_back_when_the_gpu_is_busy(ctx, capsys):
 
 
 def test_cluster_solve_abort_path_redoes_the_solve_launch_by_launch(ctx):
-    """Deterministic exercise of the give-up path (test hook NOS_TEST_CLUSTER_ABORT raises `abort` before the launch):
+    """Deterministic exercise of the give-up path (test hook: context option debug_cluster_abort raises `abort` before the launch):
     the launch leaves without a result, the host resets the shared words and redoes the solve with one launch per
     iteration; the next solve uses the one-launch form again."""
     ds = NdtDataset.from_planes(ctx, synth.ndt_planes(30_000, 900), "f64")
     good = ds.solve6(np.eye(3), np.zeros(3), EXP, max_iterations=40)
     assert good[2]["launches"] == 1
-    os.environ["NOS_TEST_CLUSTER_ABORT"] = "1"
-    try:
+    with ctx.options(debug_cluster_abort=1):
         redo = ds.solve6(np.eye(3), np.zeros(3), EXP, max_iterations=40)
-    finally:
-        del os.environ["NOS_TEST_CLUSTER_ABORT"]
     assert redo[2]["launches"] > 1 and redo[2]["ok"] and redo[2]["iterations"] == good[2]["iterations"]
     dt, dq = helpers.pose_delta(redo[0].reshape(3, 3), redo[1], good[0].reshape(3, 3), good[1])
     assert dt < 1e-10 and dq < 1e-10, (dt, dq)

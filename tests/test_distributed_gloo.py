@@ -163,11 +163,14 @@ def test_mailbox_allreduce_ranks_agree_bitwise_and_match_one_process(tmp_path, w
     ctx.close()
 
 
-def _mailbox_lonely_worker(_rank, name, out_dir):
+def _mailbox_lonely_worker(rank, name, out_dir):
     import numpy as np
     from nonlinear_optimizer_for_slam_amd import Context, NdtDataset, _lib, synth
     ctx = Context((0,))
-    ctx.comm_init_shm(2, 0, name)      # rank 1 never shows up
+    ctx.comm_init_shm(2, rank, name)
+    if rank == 1:                      # attaches, then leaves without ever taking part in an exchange
+        ctx.close()
+        return
     ds = NdtDataset.from_planes(ctx, synth.ndt_planes(5000, 100), "f64")
     import time
     t0 = time.time()
@@ -188,8 +191,60 @@ def test_mailbox_allreduce_reports_a_missing_peer_instead_of_hanging(tmp_path):
     from nonlinear_optimizer_for_slam_amd import api
     name = "/nos_test_%s" % uuid.uuid4().hex
     try:
-        mp.spawn(_mailbox_lonely_worker, args=(name, str(tmp_path)), nprocs=1, join=True)
+        mp.spawn(_mailbox_lonely_worker, args=(name, str(tmp_path)), nprocs=2, join=True)
     finally:
         api.shm_unlink(name)
     seconds, msg = open(tmp_path / "lonely.txt").read().split("\n")[:2]
     assert "timed out" in msg and 6.0 < float(seconds) < 25.0, (seconds, msg)
+
+
+def _mailbox_no_show_worker(_rank, name, out_dir):
+    from nonlinear_optimizer_for_slam_amd import Context, _lib
+    import time
+    os.environ["NOS_SHM_ATTACH_TIMEOUT_MS"] = "2500"
+    ctx = Context((0,))
+    t0 = time.time()
+    try:
+        ctx.comm_init_shm(2, 0, name)  # rank 1 never shows up
+        msg = "no error"
+    except _lib.NosError as exc:
+        msg = str(exc)
+    with open(os.path.join(out_dir, "noshow.txt"), "w") as f:
+        f.write("%.1f\n%s\n" % (time.time() - t0, msg))
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_mailbox_attach_gives_up_when_a_rank_never_comes(tmp_path):
+    import uuid
+    from nonlinear_optimizer_for_slam_amd import api
+    name = "/nos_test_%s" % uuid.uuid4().hex
+    try:
+        mp.spawn(_mailbox_no_show_worker, args=(name, str(tmp_path)), nprocs=1, join=True)
+    finally:
+        api.shm_unlink(name)
+    seconds, msg = open(tmp_path / "noshow.txt").read().split("\n")[:2]
+    assert "did not attach" in msg and 2.0 < float(seconds) < 10.0, (seconds, msg)
+
+
+@pytest.mark.gpu
+def test_mailbox_is_not_fooled_by_a_stale_segment_of_the_same_name(tmp_path):
+    """a segment left behind by a crashed run (flag words already equal to the first round numbers, slots
+    full of old sums) must not leak into a new communicator that reuses the name: rank 0 creates a FRESH segment and the
+    other ranks only join a mapping rank 0 has acknowledged."""
+    from nonlinear_optimizer_for_slam_amd import api
+    world, n = 2, 30_001
+    name = "/nos_test_stale_segment"
+    stale = np.full(4096 // 8, 1.0)            # sums = 1.0 everywhere ...
+    stale.view(np.uint64)[32::64] = 1          # ... and every flag word already says "round 1"
+    with open("/dev/shm" + name, "wb") as f:
+        f.write(stale.tobytes())
+    try:
+        mp.spawn(_mailbox_worker, args=(world, name, n, str(tmp_path)), nprocs=world, join=True)
+    finally:
+        api.shm_unlink(name)
+    ranks = [np.load(tmp_path / ("mail_rank%d.npz" % r)) for r in range(world)]
+    for r in ranks:
+        assert int(r["ok"]) == 1
+        np.testing.assert_array_equal(r["probe"], [world * (world + 1) / 2.0, float(world)])
+        assert np.array_equal(r["out"], ranks[0]["out"]) and np.array_equal(r["t"], ranks[0]["t"])

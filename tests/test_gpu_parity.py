@@ -524,13 +524,8 @@ def test_host_pack_ingestion_equals_device_unpack(ctx, dtype):
     offs = [0, 8, 16, 128, 136, 144] + [224 + 8 * (3 * j + i) for i in range(3) for j in range(3)]
     got = {}
     for mode in ("unpack", "pack"):
-        os.environ["NOS_INGEST"] = mode
-        os.environ["NOS_INGEST_THREADS"] = "5"
-        try:
+        with ctx.options(ingest={"pack": 1, "unpack": 2}[mode], ingest_threads=5):
             ds = NdtDataset.from_records(ctx, rec, 304, offs, dtype)
-        finally:
-            del os.environ["NOS_INGEST"]
-            del os.environ["NOS_INGEST_THREADS"]
         from nonlinear_optimizer_for_slam_amd import api
         got[mode] = (api.download(ds), ds.accumulate6(R_TEST, T_TEST, ("exponential", 1.0, 1.0)))
         ds.close()
@@ -538,3 +533,54 @@ def test_host_pack_ingestion_equals_device_unpack(ctx, dtype):
     assert np.array_equal(got["pack"][1], got["unpack"][1])
     if dtype == "f64":
         assert np.array_equal(got["pack"][0], planes)
+
+
+@pytest.mark.gpu
+def test_two_threads_each_owning_a_solver_get_the_single_thread_answers(oracle):
+    """the drop-in solver objects share one context per device list (AcquireRuntime); every C-ABI entry point
+    now holds the context's lock, so threads that each own a solver object take turns instead of racing on the
+    per-slot sequence words / partial rows / loop state.  The reference's solver objects are independent per instance.
+    Two threads x 12 solves each on different data (one-launch form, launch-per-iteration form and a reprojection
+    solve interleaved) must reproduce, bit for bit, what each gets alone."""
+    import threading
+    from nonlinear_optimizer_for_slam_amd import solvers, synth
+    jobs = {
+        "ndt_small": ("ndt", synth.ndt_planes(20_000, 700), ("exponential", 1.0, 1.0)),
+        "ndt_large": ("ndt", synth.ndt_planes(300_000, 9000), ("huber", 0.8)),
+        "reproj": ("reproj", synth.reproj_planes(50_000), ("huber", synth.REPROJ_HUBER_THRESHOLD)),
+    }
+
+    def solve_once(kind, planes, loss):
+        if kind == "ndt":
+            s = solvers.MahalanobisDistanceMinimizerHip()
+            s.SetLossFunction(loss)
+            pose = solvers.Pose()
+            assert s.Solve(solvers.Options(), planes, pose)
+        else:
+            s = solvers.ReprojectionErrorMinimizerHip()
+            s.SetLossFunction(loss)
+            pose = solvers.Pose()
+            assert s.Solve(solvers.Options(), planes, synth.REPROJ_INTRINSICS, pose)
+        return pose.R.copy(), pose.t.copy(), s.report.iterations, s.report.printed_cost
+
+    alone = {k: solve_once(*v) for k, v in jobs.items()}
+    errors = []
+
+    def worker(order):
+        try:
+            for _ in range(4):
+                for k in order:
+                    R, t, it, cost = solve_once(*jobs[k])
+                    if not (np.array_equal(R, alone[k][0]) and np.array_equal(t, alone[k][1]) and it == alone[k][2]
+                            and cost == alone[k][3]):
+                        errors.append((k, it, alone[k][2], float(np.max(np.abs(t - alone[k][1])))))
+        except Exception as exc:  # noqa: BLE001
+            errors.append(repr(exc))
+
+    threads = [threading.Thread(target=worker, args=(o,)) for o in
+               (("ndt_small", "reproj", "ndt_large"), ("ndt_large", "ndt_small", "reproj"))]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:5]

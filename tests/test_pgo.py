@@ -210,7 +210,7 @@ def test_large_graph_generator_and_gpu_loop(ctx):
 @pytest.mark.gpu
 def test_pcg_with_device_resident_scalars_equals_host_scalar_pcg(ctx):
     """The CG scalars (alpha, beta, r.z) live on the device by default and the host looks at |r| every 8th iteration;
-    NOS_PGO_HOST_SCALARS=1 restores the per-iteration readback.  Same arithmetic: at a fixed iteration count (a multiple
+    the context option pgo_host_scalars = 1 restores the per-iteration readback.  Same arithmetic: at a fixed iteration count (a multiple
     of 8, tolerance 0) the two must agree to rounding, and both must reach the direct solve."""
     import os
     d = op.random_graph(400, 3, seed=9)
@@ -219,11 +219,8 @@ def test_pcg_with_device_resident_scalars_equals_host_scalar_pcg(ctx):
     gpu.linearize()
     it_dev, res_dev, _ = gpu.solve(1e-4, 64, 0.0)
     x_dev = gpu.vector("step").copy()
-    os.environ["NOS_PGO_HOST_SCALARS"] = "1"
-    try:
+    with ctx.options(pgo_host_scalars=1):
         it_host, res_host, _ = gpu.solve(1e-4, 64, 0.0)
-    finally:
-        del os.environ["NOS_PGO_HOST_SCALARS"]
     x_host = gpu.vector("step").copy()
     assert it_dev == it_host == 64
     np.testing.assert_allclose(x_dev, x_host, rtol=0, atol=1e-12 * np.max(np.abs(x_host)))

@@ -328,11 +328,8 @@ def test_hash_table_and_dense_grid_lookups_give_identical_matches(ctx):
     t = np.array([0.4, -0.3, 0.2])
     res = {}
     for dense in ("1", "0"):
-        os.environ["NOS_MATCH_DENSE"] = dense
-        try:
+        with ctx.options(match_dense=int(dense)):
             m = api.NdtMap(ctx, means, S, valid, 1.0)
-        finally:
-            del os.environ["NOS_MATCH_DENSE"]
         sc = api.Scan(ctx, pts)
         ds, nm = m.match(sc, R, t, 2, "f64")
         res[dense] = (api.download(ds), nm)
