@@ -1,25 +1,30 @@
 #!/usr/bin/env python3
-"""Headline benchmark: Gauss-Newton / LM iterations of the 6-DoF NDT solver on MI355X.
+"""Headline benchmark: Gauss-Newton / LM iterations of the reference's pose solvers on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--problem ndt6|ndt3|reproj] [--dtype f64|f32] [--repeats R]
 
-One "step" is one full LM iteration of MahalanobisDistanceMinimizer (6-DoF, fp64, robust
-ExponentialLossFunction(1,1)) over the rank's resident correspondences: assemble kernel (residual +
-analytic Jacobian + weight + 28-scalar reduction) → final reduce → [N>1: one RCCL all-reduce of the 28
-doubles] → 224-byte readback → host damping + 6x6 LDLT + pose update + lambda schedule.  The dataset is
-uploaded before the timed region (inputs resident in HBM).
+One "step" is one full LM iteration over the rank's resident correspondences: assemble kernel (residual +
+analytic Jacobian + robust weight + 28- / 10-scalar reduction) → in-launch final reduce → [N > 1: one all-reduce of the
+28 doubles] → damping + 6x6 (3x3) LDLT + pose update + lambda schedule.  The dataset is uploaded before the timed
+region (inputs resident in HBM).  W untimed warm-up steps, then R trains of EXACTLY K steps, every train bracketed by
+device synchronisation (+ a barrier for N > 1) on both sides, MAX over ranks; `value` comes from the MEDIAN train and
+min / median / max are reported beside it.
 
-Workload: BASELINE.json configs[1] — 10 M synthetic correspondences over 200 k NDT voxels per GPU
-(weak scaling: configs[3] is 8 x 10 M = 80 M over 8 GPUs), generator of SURVEY.md §8d.
+Problems (BASELINE.json configs):
+  ndt6    configs[1]  mahalanobis_distance_minimizer 6-DoF, 10 M correspondences / 200 k voxels per GPU, fp64,
+                      ExponentialLossFunction(1,1) — the headline metric; x N GPUs = configs[3] (weak scaling)
+  ndt3    same data through the planar (x, y, yaw) solver
+  reproj  configs[2]  reprojection_error_minimizer, 2 M 3D<->2D correspondences, HuberLossFunction(1 px)
+Synthetic data of SURVEY.md §8d; `value` = correspondences (residual blocks) per second of the whole job.
 
-Prints ONE JSON line on rank 0.  `value` = correspondences (3-vector residual blocks) processed per
-second by the whole job; scalar residuals/s = 3x that; GN iterations/s = steps / elapsed.
+Prints ONE JSON line on rank 0.  The CPU oracle (oracle/) is imported only inside cpu_baseline(), as the thing
+TIMED beside the GPU, never as part of the GPU path.
 """
 import argparse
 import ctypes
 import json
-import math
 import os
+import statistics
 import sys
 import time
 
@@ -29,11 +34,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+HBM_PEAK_GBPS = 8000.0           # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 HBM_MEASURED_COPY_GBPS = 6290.0  # same guide: measured float4 copy
-BYTES_PER_CORR = {"f64": 120, "f32": 60}  # 15 planes x sizeof(element), SURVEY.md §8d
 N_VOXELS = 200_000
-LOSS = ("exponential", 1.0, 1.0)
+EXP = ("exponential", 1.0, 1.0)
 
 
 def parse_args():
@@ -41,55 +45,252 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--points", type=int, default=10_000_000, help="correspondences per GPU")
+    ap.add_argument("--repeats", type=int, default=5, help="trains of --steps timed steps (min / median / max reported)")
+    ap.add_argument("--problem", default="ndt6", choices=["ndt6", "ndt3", "reproj"])
+    ap.add_argument("--points", type=int, default=0, help="correspondences per GPU (0 = the config's size)")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--layout", default="flat", choices=["flat", "indexed"],
-                    help="flat = the reference's data model (120 B/corr, the headline); indexed = additive "
-                         "voxel-indexed layout (28 B/point fp64), reported separately")
+                    help="flat = the reference's data model (the headline); indexed = additive voxel-indexed layout "
+                         "(ndt6 only), reported separately")
     ap.add_argument("--loop", default="device", choices=["device", "host"],
-                    help="device: LM loop resident on the GPU (nos_ndt6_solve, the product default); "
-                         "host: the loop on the host around nos_ndt6_accumulate")
+                    help="device: LM loop resident on the GPU (nos_*_solve, the product default); host: the loop on the "
+                         "host around nos_*_accumulate (north_star's literal arrangement)")
     ap.add_argument("--prewarm-ms", type=float, default=400.0,
-                    help="untimed GPU activity (the same iteration) before the W warm-up steps: the part needs ≈ 0.1-0.3 s "
-                         "of load to reach its steady clocks (tools/clock_ramp_probe.py); reported as prewarm_ms")
+                    help="untimed GPU activity (the same iteration) before the warm-up steps: the part needs ≈ 0.1-0.3 s "
+                         "of load to reach its steady clocks; reported as prewarm_ms")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="time budget per CPU baseline leg")
+    ap.add_argument("--no-strong-baseline", action="store_true",
+                    help="skip the 80 M-correspondence single-GPU pass (denominator of the 8-GPU strong-scaling claim)")
+    ap.add_argument("--strong-points", type=int, default=80_000_000)
+    ap.add_argument("--no-cold", action="store_true", help="skip the cold (evicted) / warm single-launch measurement")
     return ap.parse_args()
 
 
-def cpu_baseline(planes, seconds):
-    """The reference's CPU paths restated (oracle/), timed on this host: AVX2+FMA fp32 over all
-    cores with the reference's thread partition, and the scalar fp64 class on one core.
-    Runs on rank 0 at N=1 only; the oracle is used here as the thing being TIMED AS A BASELINE,
-    never as part of the GPU path."""
+# ----------------------------------------------------------------------------------------------------------- workloads
+
+class Workload:
+    """One problem of the path: data, device-resident and host loops, algorithmic bytes, CPU baselines."""
+
+    def __init__(self, args, pkg):
+        self.args = args
+        self.pkg = pkg
+        self.dtype = args.dtype
+        self.elem = 8 if args.dtype == "f64" else 4
+        self.host = pkg["synth"].host_lib()
+        self.lossobj = pkg["solvers"].make_loss(self.loss)
+        self.pose_t = np.zeros(3)
+        self.pose_R = np.eye(3).reshape(-1).copy()
+        self.rep = np.zeros(5)
+
+    def reset_pose(self):
+        self.pose_t[:] = 0.0
+        self.pose_R[:] = np.eye(3).reshape(-1)
+
+    # the device-resident loop: tolerances 0 → exactly k iterations execute
+    def _check(self, r, k):
+        if not r["ok"] or r["iterations"] != k or r["launches"] not in (1, k):  # 1: one-launch form at small sizes
+            raise RuntimeError("device LM loop failed: %r" % (r,))
+        self.rep[:4] = [r["iterations"], r["printed_cost"], r["last_cost"], r["final_lambda"]]
+
+    def _host_check(self, ok, k, rep):
+        if not ok or int(rep[0]) != k:
+            raise RuntimeError("host LM loop failed: ok=%s iterations=%s status=%s" % (ok, rep[0], rep[4]))
+
+
+class Ndt6(Workload):
+    name, default_points, fields, residual_dim, n_out = "ndt6", 10_000_000, 15, 3, 28
+    metric = "ndt6_gauss_newton_residual_blocks_per_sec"
+    loss = EXP
+    loss_name = "ExponentialLossFunction(1,1)"
+    config_ref = "BASELINE.json configs[1]"
+
+    def describe(self, n, world):
+        return ("mahalanobis_distance_minimizer 6-DoF %s, %d points / %d NDT voxels per GPU (BASELINE.json configs[1]; "
+                "x%d GPUs = configs[3] shape)" % (self.dtype, n, N_VOXELS, world))
+
+    def kernel_name(self):
+        return "nos::assemble_kernel<Ndt6Problem<%s, exponential>>" % ("double" if self.dtype == "f64" else "float")
+
+    def planes(self, n, rank=0):
+        blocks_per_rank = (n + 65535) // 65536
+        return self.pkg["synth"].ndt_planes(n, N_VOXELS, first_block=rank * blocks_per_rank)
+
+    def dataset(self, ctx, planes):
+        if self.args.layout == "indexed":
+            _, first, inverse = np.unique(planes[3], return_index=True, return_inverse=True)
+            return self.pkg["NdtIndexedDataset"].from_arrays(ctx, planes[0:3], inverse.astype(np.int32)[None, :],
+                                                             planes[3:6, first].T.copy(), planes[6:15, first].T.copy(),
+                                                             self.dtype, sort_by_voxel=True)
+        return self.pkg["NdtDataset"].from_planes(ctx, planes, self.dtype)
+
+    def iterate_device(self, ds, k):
+        self.pose_R, self.pose_t, r = ds.solve6(self.pose_R, self.pose_t, self.loss, max_iterations=k,
+                                                gradient_tolerance=0.0, parameter_tolerance=0.0)
+        self._check(r, k)
+
+    def iterate_host(self, ds, k, t=None, R=None, rep=None):
+        t = self.pose_t if t is None else t
+        R = self.pose_R if R is None else R
+        rep = self.rep if rep is None else rep
+        dp = self.pkg["_lib"].c_double_p
+        ok = self.host.nos_host_ndt6_iterate(ds._h, ctypes.byref(self.lossobj), ctypes.c_int(k), t.ctypes.data_as(dp),
+                                             R.ctypes.data_as(dp), rep.ctypes.data_as(dp))
+        self._host_check(ok, k, rep)
+
+    def accumulate(self, ds):
+        return ds.accumulate6(np.eye(3), np.zeros(3), self.loss)
+
+    def pose_error(self, t=None, R=None):
+        return float(np.max(np.abs(np.asarray(self.pose_t if t is None else t) - self.pkg["synth"].true_pose("ndt")[1])))
+
+    def cpu_legs(self, oracle, planes):
+        R, t = np.eye(3), np.zeros(3)
+        return (lambda p32, threads: oracle.avx_ndt6_accumulate(p32, R, t, self.loss, threads=threads),
+                lambda sub: oracle.ndt6_accumulate(sub, R, t, self.loss),
+                "restates MDM/..._analytic_simd_various.cc:1300-1447 (SolveFloatIntrinsicAligned), reference thread partition "
+                "MDM/..._analytic_simd.cc:55-76", "restates MDM/..._analytic.cc:12-52")
+
+
+class Ndt3(Ndt6):
+    name, n_out = "ndt3", 10
+    metric = "ndt3_gauss_newton_residual_blocks_per_sec"
+
+    def describe(self, n, world):
+        return ("mahalanobis_distance_minimizer 3-DoF (planar) %s, %d points / %d NDT voxels per GPU — the data of "
+                "BASELINE.json configs[1] through MahalanobisDistanceMinimizerAnalytic3DOF's path" % (self.dtype, n, N_VOXELS))
+
+    def kernel_name(self):
+        return "nos::assemble_kernel<Ndt3Problem<%s, exponential>>" % ("double" if self.dtype == "f64" else "float")
+
+    def dataset(self, ctx, planes):
+        return self.pkg["NdtDataset"].from_planes(ctx, planes, self.dtype)
+
+    def iterate_device(self, ds, k):
+        R2 = np.array([self.pose_R[0], self.pose_R[1], self.pose_R[3], self.pose_R[4]])
+        R2, t2, r = ds.solve3(R2, self.pose_t[:2].copy(), self.loss, max_iterations=k, gradient_tolerance=0.0,
+                              parameter_tolerance=0.0)
+        self.pose_R[[0, 1, 3, 4]] = R2
+        self.pose_t[:2] = t2
+        self._check(r, k)
+
+    def iterate_host(self, ds, k, t=None, R=None, rep=None):
+        t = self.pose_t if t is None else t
+        R = self.pose_R if R is None else R
+        rep = self.rep if rep is None else rep
+        dp = self.pkg["_lib"].c_double_p
+        ok = self.host.nos_host_ndt3_iterate(ds._h, ctypes.byref(self.lossobj), ctypes.c_int(k), t.ctypes.data_as(dp),
+                                             R.ctypes.data_as(dp), rep.ctypes.data_as(dp))
+        self._host_check(ok, k, rep)
+
+    def accumulate(self, ds):
+        return ds.accumulate3(np.eye(2), np.zeros(2), self.loss)
+
+    def pose_error(self, t=None, R=None):
+        # the generator's true pose is a full 6-DoF pose: a planar solver cannot reach it; report the planar part only
+        tt = self.pkg["synth"].true_pose("ndt")[1]
+        return float(np.max(np.abs(np.asarray(self.pose_t if t is None else t)[:2] - tt[:2])))
+
+    def cpu_legs(self, oracle, planes):
+        R2, t2 = np.eye(2), np.zeros(2)
+        return (lambda p32, threads: oracle.avx_ndt3_accumulate(p32, R2, t2, self.loss, threads=threads),
+                lambda sub: oracle.ndt3_accumulate(sub, R2, t2, self.loss),
+                "restates MDM/..._analytic_3dof_simd.cc:85-158 (single-threaded in the reference: the thread fan-out "
+                "reuses the 6-DoF partition)", "restates MDM/..._analytic_3dof.cc:36-69,110-139")
+
+
+class Reproj(Workload):
+    name, default_points, fields, residual_dim, n_out = "reproj", 2_000_000, 5, 2, 28
+    metric = "reprojection_gauss_newton_residual_blocks_per_sec"
+    loss_name = "HuberLossFunction(1 px = 1/525)"
+    config_ref = "BASELINE.json configs[2]"
+
+    @property
+    def loss(self):
+        return ("huber", self.pkg["synth"].REPROJ_HUBER_THRESHOLD)
+
+    def describe(self, n, world):
+        return ("reprojection_error_minimizer %s, %d 3D<->2D correspondences, Huber loss (BASELINE.json configs[2])"
+                % (self.dtype, n))
+
+    def kernel_name(self):
+        return "nos::assemble_kernel<ReprojProblem<%s, huber>>" % ("double" if self.dtype == "f64" else "float")
+
+    def planes(self, n, rank=0):
+        return self.pkg["synth"].reproj_planes(n)
+
+    def dataset(self, ctx, planes):
+        return self.pkg["ReprojDataset"].from_planes(ctx, planes, self.dtype)
+
+    def iterate_device(self, ds, k):
+        self.pose_R, self.pose_t, r = ds.solve(self.pose_R, self.pose_t, self.pkg["synth"].REPROJ_INTR4, self.loss,
+                                               max_iterations=k, gradient_tolerance=0.0, parameter_tolerance=0.0)
+        self._check(r, k)
+
+    def iterate_host(self, ds, k, t=None, R=None, rep=None):
+        t = self.pose_t if t is None else t
+        R = self.pose_R if R is None else R
+        rep = self.rep if rep is None else rep
+        dp = self.pkg["_lib"].c_double_p
+        intr = np.array(self.pkg["synth"].REPROJ_INTR4)
+        ok = self.host.nos_host_reproj_iterate(ds._h, intr.ctypes.data_as(dp), ctypes.byref(self.lossobj),
+                                               ctypes.c_double(0.03), ctypes.c_int(k), t.ctypes.data_as(dp),
+                                               R.ctypes.data_as(dp), rep.ctypes.data_as(dp))
+        self._host_check(ok, k, rep)
+
+    def accumulate(self, ds):
+        return ds.accumulate(np.eye(3), np.zeros(3), self.pkg["synth"].REPROJ_INTR4, self.loss)
+
+    def pose_error(self, t=None, R=None):
+        # the solver estimates the INVERSE of the generator's pose: compare -R^T t with the true translation
+        R = (self.pose_R if R is None else R).reshape(3, 3)
+        tt = np.asarray(self.pose_t if t is None else t)
+        return float(np.max(np.abs(-R.T @ tt - self.pkg["synth"].true_pose("reproj")[1])))
+
+    def cpu_legs(self, oracle, planes):
+        R, t = np.eye(3), np.zeros(3)
+        intr = np.array(self.pkg["synth"].REPROJ_INTR4)
+        return (lambda p32, threads: oracle.avx_reproj_accumulate(p32, R, t, intr, self.loss, threads=threads),
+                lambda sub: oracle.reproj_accumulate(sub, R, t, intr, self.loss),
+                "restates REM/..._analytic_simd.cc:55-138 (single-threaded in the reference: the thread fan-out reuses "
+                "the 6-DoF partition)", "restates REM/..._analytic.cc:31-64,107-162")
+
+
+WORKLOADS = {"ndt6": Ndt6, "ndt3": Ndt3, "reproj": Reproj}
+
+
+# --------------------------------------------------------------------------------------------------------- CPU baseline
+
+def cpu_baseline(work, planes, seconds):
+    """The reference's CPU paths restated (oracle/), timed on this host: AVX2+FMA fp32 lanes over the host's cores with
+    the reference's thread partition, the same on one thread, and the scalar fp64 class on one core.  Rank 0 at N = 1
+    only; the oracle is the thing being TIMED AS A BASELINE here, never part of the GPU path."""
     from oracle import loader as oracle
     n = planes.shape[1]
-    R = np.eye(3)
-    t = np.zeros(3)
+    avx_fn, scalar_fn, avx_cite, scalar_cite = work.cpu_legs(oracle, planes)
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    # a one-GPU box shares its host with other jobs: stay within a fair CPU share unless told otherwise
-    cores = max(1, min(avail, int(os.environ.get("NOS_BENCH_CPU_THREADS", "32"))))
+    # default: every core this process may use (north_star: "the box's host cores"); NOS_BENCH_CPU_THREADS caps it
+    cores = max(1, min(avail, int(os.environ.get("NOS_BENCH_CPU_THREADS", str(avail)))))
     p32 = planes.astype(np.float32)
-    oracle.avx_ndt6_accumulate(p32[:, :80_000], R, t, LOSS, threads=cores)  # warm the pool / pages
-    passes, t0 = 0, time.perf_counter()
-    while True:
-        oracle.avx_ndt6_accumulate(p32, R, t, LOSS, threads=cores)
-        passes += 1
-        el = time.perf_counter() - t0
-        if el >= seconds and passes >= 2:
-            break
+    avx_fn(p32[:, :80_000], cores)  # warm the pages / threads
+
+    def timed(fn, budget, min_passes=2):
+        passes, t0 = 0, time.perf_counter()
+        while True:
+            fn()
+            passes += 1
+            el = time.perf_counter() - t0
+            if el >= budget and passes >= min_passes:
+                return passes, el
+
+    passes, el = timed(lambda: avx_fn(p32, cores), seconds)
     avx = {"value": n * passes / el, "unit": "corr/s", "cores": cores, "kind": "port",
-           "sample": "%d full passes over the same %d-correspondence workload, AVX2+FMA fp32 lanes "
-                     "(restates ..._analytic_simd_various.cc:1300-1447), %d threads of %d visible cores, reference "
-                     "thread partition" % (passes, n, cores, avail)}
-    # the same AVX2 path on ONE thread (SURVEY §8d asks for T = all and T = 1)
-    passes1, t0 = 0, time.perf_counter()
-    while True:
-        oracle.avx_ndt6_accumulate(p32, R, t, LOSS, threads=1)
-        passes1 += 1
-        el1 = time.perf_counter() - t0
-        if el1 >= 0.4 * seconds and passes1 >= 2:
-            break
+           "sample": "%d full passes over the same %d-correspondence workload, AVX2+FMA fp32 lanes (%s), %d threads of %d "
+                     "visible cores" % (passes, n, avx_cite, cores, avail)}
+    if cores > 32:  # the same at 32 threads (round 1's figure, comparable across boxes)
+        p32n, el32 = timed(lambda: avx_fn(p32, 32), 0.4 * seconds)
+        avx["threads32_value"] = n * p32n / el32
+    passes1, el1 = timed(lambda: avx_fn(p32, 1), 0.4 * seconds)
     avx["one_thread_value"] = n * passes1 / el1
     try:
         with open("/proc/cpuinfo") as f:
@@ -99,22 +300,15 @@ def cpu_baseline(planes, seconds):
     del p32
     ns = min(n, 4_000_000)
     sub = np.ascontiguousarray(planes[:, :ns])
-    passes, t0 = 0, time.perf_counter()
-    while True:
-        oracle.ndt6_accumulate(sub, R, t, LOSS)
-        passes += 1
-        el = time.perf_counter() - t0
-        if el >= seconds and passes >= 2:
-            break
+    passes, el = timed(lambda: scalar_fn(sub), seconds)
     scalar = {"value": ns * passes / el, "unit": "corr/s", "cores": 1, "kind": "port",
-              "sample": "%d passes over the first %d correspondences, scalar fp64 "
-                        "(restates ..._analytic.cc:12-52)" % (passes, ns)}
+              "sample": "%d passes over the first %d correspondences, scalar fp64 (%s)" % (passes, ns, scalar_cite)}
     return avx, scalar
 
 
 class _StdoutToStderr:
-    """RCCL prints a version banner on stdout at communicator creation; keep stdout for the one
-    JSON line by pointing fd 1 at stderr while communicators are being set up."""
+    """RCCL prints a version banner on stdout at communicator creation; keep stdout for the one JSON line by pointing
+    fd 1 at stderr while communicators are being set up."""
 
     def __enter__(self):
         sys.stdout.flush()
@@ -127,6 +321,32 @@ class _StdoutToStderr:
         os.close(self._saved)
 
 
+def check_runtime(api, need_rccl):
+    """One ROCm in the process: the HIP runtime mapped in must be the one libnos_hip.so was built with (major.minor) and
+    — when RCCL is used — librccl must come from the same directory.  A mixed process (e.g. torch's bundled runtime under
+    a library built with the system hipcc) is refused loudly; NOS_BENCH_ALLOW_SKEW=1 turns the refusal into a warning."""
+    info = api.runtime_info()
+    problems = []
+    if not info["runtime_matches_build"]:
+        problems.append("HIP runtime %d (%s) is not the ROCm libnos_hip.so was built with (%d)"
+                        % (info["runtime_hip_version"], info["hip_runtime_path"], info["build_hip_version"]))
+    if need_rccl and not info["same_rocm_tree"]:
+        problems.append("librccl (%s) and the HIP runtime (%s) come from different ROCm trees"
+                        % (info["rccl_path"], info["hip_runtime_path"]))
+    if problems:
+        msg = "[bench] ROCm version skew in this process: " + "; ".join(problems)
+        if os.environ.get("NOS_BENCH_ALLOW_SKEW", "0") != "1":
+            raise SystemExit(msg + " — refusing to measure (load libnos_hip.so before torch so that the system runtime "
+                                   "is the one mapped in, or set NOS_BENCH_ALLOW_SKEW=1)")
+        print(msg, file=sys.stderr)
+    info["skew"] = bool(problems)
+    return info
+
+
+def summarize(values):
+    return {"min": min(values), "median": statistics.median(values), "max": max(values), "n": len(values)}
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -134,75 +354,120 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    from nonlinear_optimizer_for_slam_amd import (Context, NdtDataset, NdtIndexedDataset, _lib, distributed, solvers,
-                                                  synth)
-
-    # torch is only the launcher-side plumbing for N > 1 (process group, barrier, max-over-ranks); the N = 1 path
-    # does not touch it, so the bench does not depend on torch's own view of the GPU.
-    torch = None
-    dist = None
-    force_dist = os.environ.get("NOS_BENCH_FORCE_DIST", "0") == "1"  # exercise the N>1 code path on one GPU
-    # NOS_BENCH_SHARED_GPU=1: rehearsal of the N > 1 path on a one-GPU box — every rank uses device 0 and the launcher
-    # side runs over gloo (RCCL refuses two ranks on one device); the data path (mailbox exchange) is the real one.
-    shared_gpu = os.environ.get("NOS_BENCH_SHARED_GPU", "0") == "1"
-    tdev = "cpu" if shared_gpu else "cuda"
+    if world > 1 and (args.problem != "ndt6" or args.layout != "flat"):
+        raise SystemExit("N > 1 is the sharded 6-DoF NDT configuration (configs[3]); --problem %s runs at N = 1" % args.problem)
+    # libnos_hip.so FIRST: the process then runs on the ROCm the library was built with (the system one) and the library
+    # binds the librccl that sits next to that runtime.  torch comes in afterwards and only as launcher-side plumbing
+    # (gloo process group for the barrier / max-over-ranks / the 128-byte RCCL id): it never touches the GPU here.
+    from nonlinear_optimizer_for_slam_amd import (Context, NdtDataset, NdtIndexedDataset, ReprojDataset, _lib, api,
+                                                  distributed, solvers, synth)
+    pkg = {"Context": Context, "NdtDataset": NdtDataset, "NdtIndexedDataset": NdtIndexedDataset,
+           "ReprojDataset": ReprojDataset, "_lib": _lib, "api": api, "distributed": distributed, "solvers": solvers,
+           "synth": synth}
+    shared_gpu = os.environ.get("NOS_BENCH_SHARED_GPU", "0") == "1"  # rehearsal: every rank on device 0 of a one-GPU box
+    force_dist = os.environ.get("NOS_BENCH_FORCE_DIST", "0") == "1"  # exercise the N > 1 code path with one rank
     if shared_gpu:
         local_rank = 0
-    if world > 1 or force_dist:
+    ctx = Context((local_rank,))
+    multi = world > 1 or force_dist
+    runtime = check_runtime(api, need_rccl=multi and not shared_gpu)
+
+    dist = torch = None
+    if multi:
         import torch
         import torch.distributed as dist
         if force_dist and world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
         with _StdoutToStderr():
-            if shared_gpu:
-                dist.init_process_group("gloo", rank=rank, world_size=world)
-            else:
-                torch.cuda.set_device(local_rank)
-                dist.init_process_group("nccl", rank=rank, world_size=world,
-                                        device_id=torch.device("cuda", local_rank))
-                probe = torch.ones(1, device="cuda")
-                dist.all_reduce(probe)  # creates torch's communicator (and its banner) now
-                torch.cuda.synchronize()
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        runtime_after = api.runtime_info()
+        if runtime_after["hip_runtime_path"] != runtime["hip_runtime_path"]:
+            raise SystemExit("[bench] importing torch changed the HIP runtime of the process: %r" % (runtime_after,))
 
-    n_local = args.points
-    blocks_per_rank = (n_local + 65535) // 65536
-    planes = synth.ndt_planes(n_local, N_VOXELS, first_block=rank * blocks_per_rank)
-    ctx = Context((local_rank,))
-    if args.layout == "indexed":
-        # same correspondences, stored as {point, voxel id} + voxel table; the generator's voxel of a point is
-        # identified by its mean (x coordinate is unique per voxel)
-        _, first, inverse = np.unique(planes[3], return_index=True, return_inverse=True)
-        ds = NdtIndexedDataset.from_arrays(ctx, planes[0:3], inverse.astype(np.int32)[None, :], planes[3:6, first].T.copy(),
-                                           planes[6:15, first].T.copy(), args.dtype, sort_by_voxel=True)
-    else:
-        ds = NdtDataset.from_planes(ctx, planes, args.dtype)
+    work = WORKLOADS[args.problem](args, pkg)
+    n_local = args.points if args.points > 0 else work.default_points
+    planes = work.planes(n_local, rank)
+    ds = work.dataset(ctx, planes)
+    keep_planes = rank == 0 and world == 1 and not args.no_cpu_baseline
+    if not keep_planes:
+        del planes
+        planes = None
 
-    # Data-path exchange for N > 1 (the 28 doubles of every iteration), best first; each candidate is brought up and
-    # self-tested on every rank and adopted only if ALL ranks succeed (collective MIN vote), else the next one is tried:
-    #   "mailbox"     sums exchanged INSIDE the assemble launch through a shared-memory mailbox (nos_ctx_comm_init_shm):
-    #                 no extra kernel, no RCCL call, no host step per iteration; the LM loop is device resident
-    #   "rccl-native" ncclAllReduce issued by libnos_hip.so on the launch stream + a one-wave step kernel
-    #   "torch.distributed"  all_reduce from a Python callback around nos_ndt6_accumulate_async (host loop)
-    # NOS_BENCH_COMM = auto (default: probe both, keep the faster) | mailbox | rccl | torch.
+    def fence():
+        ctx.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    def run_trains(iterate, bracket):
+        """prewarm → warm-up → R trains of K steps.  → dict(ms_per_step stats, kernel ms stats, launches)."""
+        t_pre = time.perf_counter()
+        iterate(50)
+        fence()
+        est = max_over_ranks(time.perf_counter() - t_pre)  # identical on every rank: the exchange inside is collective,
+        rounds = int(min(400, max(0, args.prewarm_ms * 1e-3 / max(est, 1e-6) - 1)))  # so the COUNT must be agreed on
+        for _ in range(rounds):
+            iterate(50)
+        fence()
+        prewarm_ms = 1e3 * (time.perf_counter() - t_pre)
+        work.reset_pose()
+        if args.warmup > 0:
+            iterate(args.warmup)
+        fence()
+        ms, kms, launches = [], [], 0
+        for _ in range(max(1, args.repeats)):
+            work.reset_pose()  # every train does the same work: K iterations from the initial pose
+            fence()
+            if os.environ.get("NOS_BENCH_NO_EVENTS", "0") != "1":
+                ctx.profile_begin(args.steps + 8, sample_every=0 if bracket else 4)
+            t0 = time.perf_counter()
+            iterate(args.steps)
+            fence()
+            elapsed = max_over_ranks(time.perf_counter() - t0)
+            n_timed, k_mean, _, _ = ctx.profile_end()
+            ms.append(1e3 * elapsed / args.steps)
+            if n_timed > 0:
+                kms.append(k_mean)
+                launches += n_timed
+        return {"ms_per_step": summarize(ms), "kernel_ms": summarize(kms) if kms else None, "launches_timed": launches,
+                "prewarm_ms": prewarm_ms, "final_translation_error_m": work.pose_error(), "lm_last_cost": float(work.rep[2])}
+
+    legs = {}
     comm_mode = "none"
-    comm_probe = {}
-    if dist is not None:
-        comm_mode = "torch.distributed"
-        want = os.environ.get("NOS_BENCH_COMM", "auto")
-        candidates = {"auto": ["mailbox", "rccl-native"], "mailbox": ["mailbox"], "rccl": ["rccl-native"],
-                      "torch": []}.get(want, [])
+    comm_details = {}
+    if dist is None:
+        if args.loop == "device":
+            legs["main"] = run_trains(lambda k: work.iterate_device(ds, k), bracket=True)
+        else:
+            legs["main"] = run_trains(lambda k: work.iterate_host(ds, k), bracket=False)
+    else:
+        # N > 1: the 28 doubles of every iteration are exchanged by (a) ONE RCCL all-reduce issued by libnos_hip.so on the
+        # launch stream (north_star's arrangement, the headline `value`) and (b) the in-launch shared-memory mailbox; BOTH
+        # are brought up, self-tested and timed for R trains of K steps, and both results are printed.
+        # NOS_BENCH_COMM = rccl | mailbox | torch restricts the set.
+        want = os.environ.get("NOS_BENCH_COMM", "both")
+        order = {"both": ["rccl-native", "mailbox"], "auto": ["rccl-native", "mailbox"], "rccl": ["rccl-native"],
+                 "mailbox": ["mailbox"], "torch": []}.get(want, ["rccl-native", "mailbox"])
+        if shared_gpu:
+            order = [c for c in order if c != "rccl-native"]  # RCCL refuses two ranks on one device
 
         def bring_up(candidate):
-            """Collective: init + self-test on every rank, unanimous vote.  → mean µs per all-reduce call, or None."""
-            ok, micros = 1.0, 0.0
+            ok, micros, seen = 1.0, 0.0, 0
             try:
                 with _StdoutToStderr():
                     if candidate == "mailbox":
                         ctx.comm_init_shm_from_torch()
                     else:
                         ctx.comm_init_from_torch()
-                    for k in range(120):  # many rounds: both parities of the double-buffered mailbox, ranks out of step
+                        seen = ctx.comm_rccl_count
+                    for k in range(120):  # both parities of the double-buffered mailbox, ranks out of step
                         if k == 20:
                             t_probe = time.perf_counter()
                         got = ctx.comm_allreduce([rank + 1.0, 1.0])
@@ -212,210 +477,233 @@ def main():
             except Exception as exc:  # noqa: BLE001
                 print("[bench] %s unavailable on rank %d: %s" % (candidate, rank, exc), file=sys.stderr)
                 ok = 0.0
-            vote = torch.tensor([ok, -micros], dtype=torch.float64, device=tdev)
-            dist.all_reduce(vote, op=dist.ReduceOp.MIN)   # all ranks ok, and the slowest rank's time
+            vote = torch.tensor([ok, -micros], dtype=torch.float64)
+            dist.all_reduce(vote, op=dist.ReduceOp.MIN)  # all ranks ok, and the slowest rank's time
             if float(vote[0].item()) > 0.5:
-                return -float(vote[1].item())
+                return {"allreduce_call_us": -float(vote[1].item()), "ranks_seen": seen if candidate != "mailbox" else ctx.comm_size}
             if ctx.comm_size > 0:
-                ctx.comm_destroy()  # came up here but not everywhere: drop it
+                ctx.comm_destroy()
             return None
 
-        # "auto": bring each candidate up, time 100 all-reduce calls of the 28-double payload's kind on THIS machine
-        # (same host-side wrapping for both, so the difference is the exchange itself), keep the faster one — the RCCL form
-        # is charged the ≈ 4 µs of its extra step kernel that the probe does not see.  Identical decision on every rank
-        # (the votes are all-reduced).
-        for candidate in candidates:
-            micros = bring_up(candidate)
-            if micros is not None:
-                comm_probe[candidate] = micros
-                ctx.comm_destroy()
-        if comm_probe:
-            def cost(c):
-                return comm_probe[c] + (4.0 if c == "rccl-native" else 0.0)
-            best = min(comm_probe, key=cost)
-            if bring_up(best) is not None:
-                comm_mode = best
-    if not (rank == 0 and world == 1 and not args.no_cpu_baseline):
-        del planes
-        planes = None
+        for candidate in order:
+            up = bring_up(candidate)
+            if up is None:
+                continue
+            it = (lambda k: work.iterate_device(ds, k)) if args.loop == "device" else (lambda k: work.iterate_host(ds, k))
+            legs[candidate] = run_trains(it, bracket=(candidate == "mailbox" and args.loop == "device"))
+            legs[candidate].update(up)
+            if candidate == "rccl-native":
+                legs[candidate]["ncclCommCount"] = up["ranks_seen"]
+            ctx.comm_destroy()
+        if "rccl-native" in legs:
+            comm_mode = "rccl-native"
+        elif "mailbox" in legs:
+            comm_mode = "mailbox"
+        else:
+            # last resort: torch.distributed all_reduce (gloo here) from a Python callback around nos_ndt6_accumulate
+            comm_mode = "torch.distributed(gloo)"
+            out = np.zeros(28)
 
-    host = synth.host_lib()
-    loss = solvers.make_loss(LOSS)
-    pose_t = np.zeros(3)
-    pose_R = np.eye(3).reshape(-1).copy()
-    rep = np.zeros(5)
+            def local(R, t):
+                out[:] = ds.accumulate6(R, t, work.loss)
+                return torch.from_numpy(out)
 
-    if comm_mode != "torch.distributed" and args.loop == "device":
-        def iterate(k):
-            nonlocal pose_t, pose_R
-            # tolerances 0: no convergence exit, exactly k iterations execute
-            pose_R, pose_t, r = ds.solve6(pose_R, pose_t, LOSS, max_iterations=k, gradient_tolerance=0.0,
-                                          parameter_tolerance=0.0)
-            if not r["ok"] or r["iterations"] != k or r["launches"] not in (1, k):  # 1: small --points, one-launch form
-                raise RuntimeError("device LM loop failed: %r" % (r,))
-            rep[:4] = [r["iterations"], r["printed_cost"], r["last_cost"], r["final_lambda"]]
-    elif comm_mode != "torch.distributed":
-        def iterate(k):
-            ok = host.nos_host_ndt6_iterate(ds._h, ctypes.byref(loss), ctypes.c_int(k),
-                                            pose_t.ctypes.data_as(_lib.c_double_p),
-                                            pose_R.ctypes.data_as(_lib.c_double_p),
-                                            rep.ctypes.data_as(_lib.c_double_p))
-            if not ok or int(rep[0]) != k:
-                raise RuntimeError("LM loop failed: ok=%s iterations=%s status=%s" % (ok, rep[0], rep[4]))
-    else:
-        ctx.use_torch_stream()
-        out = torch.zeros(28, dtype=torch.float64, device="cuda")
+            asm = distributed.ShardedAssembler(local)
+            pose = solvers.Pose()
 
-        def local(R, t):
-            ds.accumulate6_async(R, t, LOSS, out)
-            return out
+            def iterate_torch(k):
+                r = distributed.solve_ndt6(asm, solvers.Options(k, 0.0, 0.0), pose)
+                if r.iterations != k:
+                    raise RuntimeError("LM loop ended after %d of %d iterations" % (r.iterations, k))
+                work.rep[:4] = [r.iterations, r.printed_cost, r.last_cost, r.final_lambda]
+                work.pose_t[:], work.pose_R[:] = pose.t, pose.R.reshape(-1)
 
-        asm = distributed.ShardedAssembler(local)
-        pose = solvers.Pose()
+            legs[comm_mode] = run_trains(iterate_torch, bracket=False)
+        legs["main"] = legs[comm_mode]
+        comm_details = {k: {"ms_per_step": v["ms_per_step"], "allreduce_call_us": v.get("allreduce_call_us"),
+                            "ranks_seen": v.get("ranks_seen"), "ncclCommCount": v.get("ncclCommCount")}
+                        for k, v in legs.items() if k != "main"}
 
-        def iterate(k):
-            nonlocal pose_t, pose_R
-            r = distributed.solve_ndt6(asm, solvers.Options(k, 0.0, 0.0), pose)
-            if r.iterations != k:
-                raise RuntimeError("LM loop ended after %d of %d iterations" % (r.iterations, k))
-            rep[:4] = [r.iterations, r.printed_cost, r.last_cost, r.final_lambda]
-            pose_t, pose_R = pose.t, pose.R.reshape(-1)
+    main_leg = legs["main"]
+    ms_med = main_leg["ms_per_step"]["median"]
+    n_total = n_local * world
+    value = n_total / (ms_med * 1e-3)
+    bytes_per_launch = ds.stream_bytes  # flat: n * fields * sizeof(element); indexed: n * (3 * elem + 4)
+    kern = main_leg["kernel_ms"]
+    k_med = kern["median"] if kern else 0.0
+    achieved = bytes_per_launch / (k_med * 1e-3) / 1e9 if k_med > 0 else 0.0
+    device_loop = args.loop == "device" and comm_mode != "torch.distributed(gloo)"
+    bracket = dist is None and args.loop == "device" or (comm_mode == "mailbox" and args.loop == "device")
 
-    def fence():
-        ctx.synchronize()
-        if dist is not None:
-            if not shared_gpu:
-                torch.cuda.synchronize()
-            dist.barrier()
-
-    t_pre = time.perf_counter()
-    # a fixed number of iterations (≈ 0.2 ms each at the default size), identical on every rank: the exchange inside
-    # the iterations is collective, a time-based loop would let ranks disagree on the count
-    for _ in range(int(args.prewarm_ms / 0.2) // 50):
-        iterate(50)
-    fence()
-    prewarm_ms = 1e3 * (time.perf_counter() - t_pre)
-    pose_t[:] = 0.0                       # the warm-up and the timed steps start from the initial pose again
-    pose_R[:] = np.eye(3).reshape(-1)
-    if args.warmup > 0:
-        iterate(args.warmup)
-    fence()
-    # Kernel duration for the roofline, from HIP events on the launch stream over the timed region.  Device-resident
-    # loop at N = 1: the launches form one back-to-back train, so ONE event pair brackets the whole train (an event
-    # between two queued kernels would serialise their dispatch) and the duration per launch is train / launches — an
-    # upper bound of the kernel's own duration.  Host loop / N > 1: an event pair around every 4th assemble launch.
-    bracket = comm_mode in ("none", "mailbox") and args.loop == "device"
-    if os.environ.get("NOS_BENCH_NO_EVENTS", "0") != "1":
-        ctx.profile_begin(args.steps + 8, sample_every=0 if bracket else 4)
-    t0 = time.perf_counter()
-    iterate(args.steps)
-    fence()
-    elapsed = time.perf_counter() - t0
-    n_timed, k_mean_ms, k_min_ms, k_max_ms = ctx.profile_end()
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-
-    # Second, untimed-for-the-metric pass at N = 1: the same K steps with the loop ON THE HOST (6x6 LDLT, damping and pose
-    # update on the CPU around nos_ndt6_accumulate — the arrangement BASELINE.json's north_star describes literally), so
-    # both placements of the loop are on record from one run.
+    # ---- second placement of the loop at N = 1 (host loop beside the device loop), one train
     host_loop = None
-    if world == 1 and dist is None and args.loop == "device":
+    if dist is None and args.loop == "device":
         ht, hR, hrep = np.zeros(3), np.eye(3).reshape(-1).copy(), np.zeros(5)
-
-        def iterate_host(k):
-            ok = host.nos_host_ndt6_iterate(ds._h, ctypes.byref(loss), ctypes.c_int(k), ht.ctypes.data_as(_lib.c_double_p),
-                                            hR.ctypes.data_as(_lib.c_double_p), hrep.ctypes.data_as(_lib.c_double_p))
-            if not ok or int(hrep[0]) != k:
-                raise RuntimeError("host LM loop failed: ok=%s iterations=%s status=%s" % (ok, hrep[0], hrep[4]))
-
-        iterate_host(max(args.warmup, 1))
+        work.iterate_host(ds, max(args.warmup, 1), ht, hR, hrep)
+        ht[:], hR[:] = 0.0, np.eye(3).reshape(-1)
         ctx.synchronize()
         th = time.perf_counter()
-        iterate_host(args.steps)
+        work.iterate_host(ds, args.steps, ht, hR, hrep)
         ctx.synchronize()
         eh = time.perf_counter() - th
         host_loop = {"ms_per_step": 1e3 * eh / args.steps, "value": n_local * args.steps / eh, "unit": "corr/s",
-                     "final_translation_error_m": float(np.max(np.abs(ht - synth.true_pose("ndt")[1]))),
-                     "note": "same K steps, LM loop on the host around nos_ndt6_accumulate (north_star's literal arrangement)"}
+                     "final_translation_error_m": work.pose_error(ht, hR),
+                     "note": "same K steps, LM loop on the host around nos_%s_accumulate (north_star's literal arrangement)"
+                             % args.problem}
 
-    n_total = n_local * world
-    value = n_total * args.steps / elapsed
-    bytes_per_launch = ds.stream_bytes  # flat: n * 120 (fp64) / 60 (fp32); indexed: n * (3 * elem + 4)
-    achieved = bytes_per_launch / (k_mean_ms * 1e-3) / 1e9 if k_mean_ms > 0 else 0.0
-    Rt, tt_true = synth.true_pose("ndt")
-    pose_err = float(np.max(np.abs(np.asarray(pose_t) - tt_true)))
+    # ---- cold (evicted from the 256 MiB Infinity Cache) vs warm single launches, for datasets that fit the cache
+    cold_warm = None
+    if dist is None and not args.no_cold and args.layout == "flat" and bytes_per_launch <= (200 << 20):
+        evict_n = 4_500_000  # 540 MB of fp64 planes streamed through the cache between two timed launches
+        evictor = NdtDataset.from_planes(ctx, synth.ndt_planes(evict_n, 10_000), "f64")
+
+        def single_launch_ms(evict, reps=24):
+            out = []
+            for _ in range(reps):
+                if evict:
+                    evictor.accumulate6(np.eye(3), np.zeros(3), None)
+                ctx.profile_begin(4, sample_every=1)
+                work.accumulate(ds)
+                _, k_mean, _, _ = ctx.profile_end()
+                out.append(k_mean)
+            return summarize(out[4:])
+
+        warm, cold = single_launch_ms(False), single_launch_ms(True)
+        evictor.close()
+        cold_warm = {
+            "how": "hipEvent pair on the launch stream around ONE assemble launch (launch gap included); cold = a 540 MB "
+                   "streaming pass over another dataset between two timed launches (evicts the Infinity Cache), warm = "
+                   "launches back to back on the resident data",
+            "warm_ms": warm, "cold_ms": cold,
+            "warm_GBps": bytes_per_launch / (warm["median"] * 1e-3) / 1e9,
+            "cold_GBps": bytes_per_launch / (cold["median"] * 1e-3) / 1e9,
+        }
+
+    # ---- the denominator of the strong-scaling claim: configs[3]'s 80 M correspondences on ONE GPU
+    strong = None
+    if (dist is None and not args.no_strong_baseline and args.problem == "ndt6" and args.layout == "flat"
+            and args.dtype == "f64" and args.points in (0, 10_000_000)):
+        ds.close()
+        big_n = args.strong_points
+        big = np.empty((15, big_n))
+        per = 10_000_000
+        for r8 in range((big_n + per - 1) // per):  # the 8 ranks' blocks of configs[3], side by side
+            lo, hi = r8 * per, min(big_n, (r8 + 1) * per)
+            big[:, lo:hi] = synth.ndt_planes(hi - lo, N_VOXELS, first_block=r8 * ((per + 65535) // 65536))
+        big_ds = NdtDataset.from_planes(ctx, big, "f64")
+        del big
+        steps80 = max(10, args.steps // 8)
+        work.reset_pose()
+        work.iterate_device(big_ds, 5)
+        samples = []
+        for _ in range(3):
+            work.reset_pose()
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            work.iterate_device(big_ds, steps80)
+            ctx.synchronize()
+            samples.append(1e3 * (time.perf_counter() - t0) / steps80)
+        strong = {"points": big_n, "ms_per_step": statistics.median(samples), "ms_per_step_min": min(samples),
+                  "ms_per_step_max": max(samples), "steps": steps80, "trains": 3,
+                  "value": big_n / (statistics.median(samples) * 1e-3), "unit": "corr/s",
+                  "final_translation_error_m": work.pose_error(),
+                  "note": "configs[3]'s 80 M correspondences (the 8 ranks' blocks) resident on ONE GPU, same device loop: "
+                          "T1 of the strong-scaling ratio; 8 GPUs at 10 M each take the N = 8 line's ms_per_step"}
+        big_ds.close()
+        ds = None
 
     result = {
-        "metric": "ndt6_gauss_newton_residual_blocks_per_sec",
+        "metric": work.metric,
         "value": value,
         "unit": "corr/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps,
-        "prewarm_ms": prewarm_ms,
+        "ms_per_step": ms_med,
+        "ms_per_step_trains": main_leg["ms_per_step"],
+        "prewarm_ms": main_leg["prewarm_ms"],
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": args.dtype,
         "data": "synthetic",
         "config": {
-            "workload": "mahalanobis_distance_minimizer 6-DoF %s, %d points / %d NDT voxels per GPU "
-                        "(BASELINE.json configs[1]; x%d GPUs = configs[3] shape)%s"
-                        % (args.dtype, n_local, N_VOXELS, world,
-                           "" if args.layout == "flat" else " — ADDITIVE voxel-indexed layout, not the 120-B/corr headline"),
-            "layout": args.layout,
-            "points_per_gpu": n_local, "total_points": n_total, "voxels": N_VOXELS,
-            "loss": "ExponentialLossFunction(1,1)", "parallelism": "corr-shard x%d, all-reduce 28 f64" % world,
+            "workload": work.describe(n_local, world) + ("" if args.layout == "flat" else
+                                                        " — ADDITIVE voxel-indexed layout, not the 120-B/corr headline"),
+            "problem": args.problem, "layout": args.layout,
+            "points_per_gpu": n_local, "total_points": n_total,
+            "loss": work.loss_name,
+            "parallelism": "corr-shard x%d, all-reduce %d f64" % (world, work.n_out),
             "collective": comm_mode,
-            "collective_probe_us_per_allreduce_call": comm_probe,
-            "loop": args.loop if comm_mode != "torch.distributed" else "host",
-            "step": ("LM iteration, device resident: assemble kernel + in-launch final reduce%s + 6x6 LDLT / pose update "
-                     "/ lambda schedule on the GPU, next launch already queued"
-                     % ("" if world == 1 else (" + in-launch mailbox all-reduce(28 f64)" if comm_mode == "mailbox"
+            "collectives_timed": comm_details,
+            "value_is": ("median of %d trains of %d steps" % (main_leg["ms_per_step"]["n"], args.steps))
+                        + ("" if world == 1 else "; exchange = %s%s" % (
+                            comm_mode, " (north_star: one RCCL all-reduce of the 28 doubles per iteration)"
+                            if comm_mode == "rccl-native" else "")),
+            "loop": "device" if device_loop else "host",
+            "step": ("LM iteration, device resident: assemble kernel + in-launch final reduce%s + LDLT / pose update / "
+                     "lambda schedule on the GPU, next launch already queued"
+                     % ("" if world == 1 else (" + in-launch mailbox all-reduce" if comm_mode == "mailbox"
                                                else " + RCCL all-reduce(28 f64) + step kernel")))
-                    if (args.loop == "device" and comm_mode != "torch.distributed") else
-                    ("LM iteration: assemble kernel + final reduce%s + 224 B readback + host 6x6 LDLT/pose update"
-                     % (" + RCCL all-reduce(28 f64)" if world > 1 else "")),
+                    if device_loop else
+                    ("LM iteration: assemble kernel + final reduce%s + readback + host LDLT / pose update"
+                     % (" + all-reduce(28 f64)" if world > 1 else "")),
         },
-        "scalar_residuals_per_sec": 3.0 * value,
-        "gn_iters_per_sec": args.steps / elapsed,
-        "final_translation_error_m": pose_err,
-        "lm_last_cost": float(rep[2]),
+        "scalar_residuals_per_sec": work.residual_dim * value,
+        "gn_iters_per_sec": 1e3 / ms_med,
+        "final_translation_error_m": main_leg["final_translation_error_m"],
+        "lm_last_cost": main_leg["lm_last_cost"],
+        "runtime": runtime,
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-            "kernel": "nos::assemble_kernel<Ndt6Problem<%s, exponential>>" % ("double" if args.dtype == "f64" else "float"),
-            "kernel_ms_mean": k_mean_ms, "kernel_ms_min": k_min_ms, "kernel_ms_max": k_max_ms,
-            "launches_timed": n_timed, "algorithmic_bytes_per_launch": bytes_per_launch,
+            "kernel": work.kernel_name(),
+            "kernel_ms": kern, "kernel_ms_mean": k_med,
+            "launches_timed": main_leg["launches_timed"], "algorithmic_bytes_per_launch": bytes_per_launch,
             "bytes_per_corr": bytes_per_launch / max(n_local, 1),
             "frac_of_measured_copy_6290": achieved / HBM_MEASURED_COPY_GBPS,
-            "timing": ("one hipEvent pair on the launch stream bracketing the back-to-back train of the timed steps' "
-                       "launches; duration per launch = train / launches (upper bound: includes the in-launch reduce, "
-                       "the LM step and any gap)") if bracket else
+            "note": "frac is against the 8000 GB/s spec peak; the guide's 6290 GB/s is a float4 COPY (read + write sharing "
+                    "the bus) — a read-only stream with non-temporal loads sustains more (its measured range for streaming "
+                    "reads is 6.0-6.8 TB/s); datasets below 256 MiB are Infinity-Cache resident when warm (see cold_warm)",
+            "timing": ("one hipEvent pair on the launch stream bracketing each back-to-back train of timed launches; duration "
+                       "per launch = train / launches (upper bound: includes the in-launch reduce, the LM step and any gap); "
+                       "median over the trains") if bracket else
                       "hipEvent pairs on the launch stream around every 4th assemble launch of the timed steps",
         },
     }
-    # HBM traffic per launch comes from rocprofv3 PMC passes of this same command (they cannot be
-    # collected from inside the process); use the committed summary when it is for this workload.
+    # HBM traffic per launch comes from rocprofv3 PMC passes of this same command (they cannot be collected from inside
+    # the process): taken from the newest committed summary for this problem / size / dtype, with its provenance.
     try:
         import glob
-        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_summary.json")), reverse=True):
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench*summary*.json")), reverse=True):
             prof = json.load(open(path))
-            if prof.get("points_per_gpu") == n_local and prof.get("dtype") == args.dtype and args.layout == "flat":
+            if (prof.get("points_per_gpu") == n_local and prof.get("dtype") == args.dtype and args.layout == "flat"
+                    and prof.get("problem", "ndt6") == args.problem):
                 result["roofline"]["traffic"] = prof["traffic_bytes_per_launch"]
                 result["roofline"]["traffic_source"] = (
-                    "%s: 2 x FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes (gfx950 x2 correction)"
-                    % os.path.relpath(path, ROOT))
+                    "NOT measured in this run: copied from the committed rocprofv3 profile %s (2 x FETCH_SIZE + WRITE_SIZE of "
+                    "separate --pmc passes, gfx950 x2 correction; profiled commit %s)"
+                    % (os.path.relpath(path, ROOT), prof.get("commit", "unrecorded")))
                 break
     except Exception:  # a missing / malformed summary only loses the optional field
         pass
     if host_loop is not None:
         result["host_loop"] = host_loop
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        avx, scalar = cpu_baseline(planes, args.cpu_seconds)
+    if cold_warm is not None:
+        result["cold_warm"] = cold_warm
+    if strong is not None:
+        result["strong_baseline"] = strong
+    if world > 1:
+        for name, leg in legs.items():
+            if name != "main":
+                result[name.replace("-native", "")] = {"ms_per_step": leg["ms_per_step"]["median"],
+                                                      "ms_per_step_trains": leg["ms_per_step"],
+                                                      "value": n_total / (leg["ms_per_step"]["median"] * 1e-3),
+                                                      "ncclCommCount": leg.get("ncclCommCount")}
+        result["scaling_note"] = ("weak scaling: every rank keeps %d correspondences; N > 1 numbers exist only where this "
+                                  "line was produced on N GPUs" % n_local)
+    if keep_planes:
+        avx, scalar = cpu_baseline(work, planes, args.cpu_seconds)
         result["cpu_baseline"] = avx
         result["cpu_baseline_scalar_fp64"] = scalar
         result["gpu_over_cpu_avx"] = value / avx["value"]

@@ -8,7 +8,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_HIP = os.path.join(CSRC, "libnos_hip.so")
+# NOS_HIP_LIB: an alternative build of the same library (e.g. the -DNOS_LM_TIMING probe build of tools/); default in-tree
+LIB_HIP = os.environ.get("NOS_HIP_LIB") or os.path.join(CSRC, "libnos_hip.so")
 LIB_HOST = os.path.join(CSRC, "libnos_host.so")
 
 c_double_p = ctypes.POINTER(ctypes.c_double)

@@ -1066,23 +1066,41 @@ __global__ __launch_bounds__(BLOCK) void solve_single_block_kernel(TiledLayout L
   }
 }
 
-// ---------------------------------------------------------------- whole solve in one launch, one chunk per workgroup
+// ---------------------------------------------------------------- whole solve in one launch, data resident on chip
 //
-// Between the single-workgroup form above and the sizes where a launch is mostly streaming (a few 10^5 correspondences)
-// an LM iteration through one launch per iteration costs ≈ 12.6 µs, of which the kernel boundary, the dispatch of the
-// next grid and its first loads are more than a third.  For up to kClusterMaxBlocks chunks (one 512-thread workgroup per
-// CU, all resident at once) the whole loop runs in ONE launch: every workgroup keeps its chunk in REGISTERS for all
-// iterations, the per-iteration hand-off is the same ticket scheme as in the grid kernel, the finishing workgroup runs
-// LmAdvance*, writes the new state with write-through (sc1) stores and bumps an epoch word; the other workgroups poll the
-// epoch (one lane, sc1 loads) and read the new pose with sc1 loads.  Every wait is bounded (kClusterTimeoutTicks): a
-// workgroup that waits longer — e.g. because another process holds CUs and the grid is not fully resident — raises
-// `abort` and everybody leaves; the host then re-runs the solve with one launch per iteration.
+// Between the single-workgroup form above and the sizes where a launch is mostly streaming, an LM iteration through
+// one launch per iteration costs ≈ 12 µs, nearly all of it kernel boundary, dispatch, first loads and hand-off.  Up to the
+// on-chip capacity (ResidentShape below) the whole loop runs in ONE launch instead, one 512-thread workgroup per CU, all
+// resident at once, every workgroup keeping its correspondences in REGISTERS + LDS for all iterations.
+//
+// Per iteration (an all-reduce, every workgroup for itself — nothing is broadcast):
+//   1. item math over the resident correspondences, block reduction, the row of sums goes out as write-through (sc1)
+//      stores into partials[iteration parity][workgroup];
+//   2. the storing wave drains (vmcnt(0)), one lane ARRIVES: a no-return agent-scope add on one of 8 arrival counters
+//      (workgroup index mod 8; counters are monotonic for the whole launch, each on a cache line of its own);
+//   3. 8 lanes poll the 8 counters (sc1 loads) until all stand at (iteration + 1) x group size — every row of this
+//      iteration has then left its writer (hand-off form "sc1 stores + drain + counter / sc1 loads", MI355X_MICROARCH.md);
+//   4. EVERY workgroup adds all rows in the same fixed order (sc1 loads, 16 in flight per thread) and runs the same
+//      nos_host::LmAdvance* on its own copy of the loop state: identical bits everywhere, so no state has to travel.
+// Rows are double buffered by iteration parity: a workgroup can run at most one iteration ahead of the slowest reader,
+// because arriving at iteration k + 1 happens after reading the rows of iteration k.
+// Compared with round 1's form (one finishing workgroup: tickets with returned values, row sums, LM step, state written
+// through, epoch word, everybody polls and re-reads the state) this removes two memory round trips and the state
+// broadcast from the critical path of every iteration.
+// Every wait is bounded (kClusterTimeoutTicks): a workgroup that waits longer — e.g. because another process holds CUs and
+// the grid is not fully resident — raises `abort` and everybody leaves; the host then re-runs the solve with one launch
+// per iteration.
 constexpr uint32_t kClusterMaxBlocks = 256;
 constexpr unsigned long long kClusterTimeoutTicks = 5000000ull;  // 50 ms of the 100 MHz wall clock per iteration
 
+// Control words of one resident launch, zeroed by the host before the launch (hipMemsetAsync on the launch stream).
 struct ClusterCtl {
-  unsigned int epoch;  // iterations completed (published by the finishing workgroup)
-  unsigned int abort;  // 1: a wait timed out, the launch gave up
+  unsigned int abort;           // 1: a wait timed out, the launch gave up
+  unsigned int pad0[31];
+  struct alignas(128) Arrival {
+    unsigned int count;         // arrivals of the workgroups with index mod 8 == this counter's index, all iterations
+    unsigned int pad[31];
+  } arrival[8];
 };
 
 __device__ __forceinline__ double sc1_load(const double* p) {
@@ -1109,38 +1127,84 @@ __device__ __forceinline__ void state_load_sc1(const LmDevice* lm, nos_host::LmS
   for (int k = 0; k < kWords; ++k) s[k] = sc1_load(d + k);
 }
 
-template <typename Problem, typename T, int BLOCK>
+// How many correspondences a lane keeps resident for the whole solve: RI of them in REGISTERS (compile-time unrolled) and
+// up to LI more in LDS (dynamic allocation, [slot][field][lane] so that lanes read consecutive addresses).  One
+// 512-thread workgroup per CU → two waves per SIMD → 256 VGPRs per lane and ≈ 150 KB of the CU's 160 KB LDS:
+//   NDT fp64 (120 B / correspondence): 2 + 2 → 4 per lane → 524 288 correspondences on 256 CUs
+//   NDT fp32 ( 60 B)                  : 3 + 4 → 7         → 917 504   (more register items spill: checked with
+//                                                                    tools/kernel_resources.py)
+//   reprojection fp64 (40 B)          : 9 + 7 → 16        → 2 097 152  (BASELINE.json configs[2]: 2 M)
+//   reprojection fp32 (20 B)          : 10 + 14 → 24      → 3 145 728
+// i.e. at these sizes an LM iteration touches neither HBM nor the caches: its cost is the item math plus one grid-wide
+// hand-off.  The first touch (one pass over the dataset) is paid once per solve.
+template <int FIELDS, int ELEM>
+struct ResidentShape;
+template <>
+struct ResidentShape<15, 8> { static constexpr int RI = 2, LI = 2; };
+template <>
+struct ResidentShape<15, 4> { static constexpr int RI = 3, LI = 4; };
+template <>
+struct ResidentShape<5, 8> { static constexpr int RI = 9, LI = 7; };
+template <>
+struct ResidentShape<5, 4> { static constexpr int RI = 10, LI = 14; };
+
+template <typename Problem, typename T, int BLOCK, int RI, int LI>
 __global__ __launch_bounds__(BLOCK) void solve_cluster_kernel(TiledLayout L, typename Problem::Params P,
-                                                             double* __restrict__ partials, unsigned int* counter,
-                                                             LmDevice* lm, ClusterCtl* ctl, unsigned int epoch_base,
+                                                             double* __restrict__ partials, LmDevice* lm, ClusterCtl* ctl,
                                                              double* __restrict__ cost_history, int history_capacity,
                                                              double* entry_host, unsigned long long* seq_host,
-                                                             unsigned long long seq) {
+                                                             unsigned long long seq, uint32_t items_per_lane) {
   constexpr int kF = Problem::kFields;
   constexpr int kOut = Problem::kOut;
   constexpr int kCols = 32;
   constexpr int kSlices = BLOCK / kCols;
   const T* __restrict__ base = static_cast<const T*>(L.base);
-  __shared__ unsigned int s_last;
+  extern __shared__ __align__(16) unsigned char resident_raw[];  // [items_per_lane - RI][kF][BLOCK] of T
+  T* resident = reinterpret_cast<T*>(resident_raw);
   __shared__ int s_flag;  // 0 go on, 1 loop finished, 2 abort
   __shared__ double red[kSlices][kCols];
   __shared__ double s_tot[kOut];
   __shared__ double s_pose[12];
-  __shared__ double s_state_raw[(sizeof(nos_host::LmState) + 7) / 8];  // the loop state as of the current iteration
+  __shared__ double s_state_raw[(sizeof(nos_host::LmState) + 7) / 8];  // this workgroup's copy of the loop state
   nos_host::LmState& s_state = *reinterpret_cast<nos_host::LmState*>(s_state_raw);
 
-  // this workgroup's chunk, read once
-  const uint64_t i0 = uint64_t(blockIdx.x) * BLOCK + threadIdx.x;
-  const uint64_t off = (i0 >> L.tile_shift) * L.tile_stride + (i0 & L.tile_mask);
-  T x[kF];
-  {
+  // This workgroup's correspondences, read ONCE: slot j of lane l is item  block_base + j * BLOCK + l  (a wave reads
+  // consecutive items of one field per load).  Slots beyond n are zero records (contribute exactly nothing) and are
+  // flagged invalid for the problems that mask.
+  const uint32_t J = items_per_lane;  // grid-uniform, 1 … RI + LI
+  const uint64_t block_base = uint64_t(blockIdx.x) * BLOCK * J;
+  auto fetch = [&](uint32_t j, T (&dst)[kF]) -> bool {
+    const uint64_t i = block_base + uint64_t(j) * BLOCK + threadIdx.x;
+    const bool ok = i < L.n;
+    const uint64_t ic = ok ? i : 0;  // clamped address; the value is zeroed below
+    const uint64_t off = (ic >> L.tile_shift) * L.tile_stride + (ic & L.tile_mask);
     T xt[kF][1];
 #pragma unroll
     for (int f = 0; f < kF; ++f) load_items<T, 1, false>(base + off + uint64_t(f) * L.field_stride, xt[f]);
 #pragma unroll
-    for (int f = 0; f < kF; ++f) x[f] = xt[f][0];
+    for (int f = 0; f < kF; ++f) dst[f] = ok ? xt[f][0] : T(0);
+    return ok;
+  };
+  T x[RI][kF];
+  bool valid[RI];
+#pragma unroll
+  for (int j = 0; j < RI; ++j) {
+    valid[j] = false;
+    if (uint32_t(j) < J) {
+      valid[j] = fetch(uint32_t(j), x[j]);
+    } else {
+#pragma unroll
+      for (int f = 0; f < kF; ++f) x[j][f] = T(0);
+    }
   }
-  const bool valid = i0 < L.n;
+  if constexpr (LI > 0) {
+    for (uint32_t j = RI; j < J; ++j) {
+      T xi[kF];
+      (void)fetch(j, xi);
+#pragma unroll
+      for (int f = 0; f < kF; ++f) resident[(size_t(j - RI) * kF + f) * BLOCK + threadIdx.x] = xi[f];
+    }
+  }
   const nos_host::LmSettings settings = lm->settings;  // constant during the launch
   if (threadIdx.x == 0) {
     s_state = lm->st;  // written by lm_init_kernel before this launch
@@ -1151,59 +1215,98 @@ __global__ __launch_bounds__(BLOCK) void solve_cluster_kernel(TiledLayout L, typ
     for (int k = 0; k < 3; ++k) s_pose[9 + k] = s_state.t[k];
   }
   __syncthreads();
-  unsigned int it = epoch_base;  // the epoch word is monotonic across launches (the host passes where it stands)
-  bool wrote_last = false;  // this workgroup finished the most recent iteration
+  const unsigned int group = blockIdx.x & 7u;
+  const unsigned int n_groups = gridDim.x < 8u ? gridDim.x : 8u;
+  unsigned int it = 0;
   int executed = 0;
+#ifdef NOS_LM_TIMING
+  unsigned long long tq[6] = {0, 0, 0, 0, 0, 0}, tp = 0;
+#define NOS_RES_STAMP(slot_)                                  \
+  {                                                           \
+    const unsigned long long now_ = wall_clock64();           \
+    tq[slot_] += now_ - tp;                                   \
+    tp = now_;                                                \
+  }
+#else
+#define NOS_RES_STAMP(slot_)
+#endif
   while (s_flag == 0) {
+#ifdef NOS_LM_TIMING
+    tp = wall_clock64();
+#endif
     // pose of this iteration from LDS → scalar registers
-    {
-      LmDevice* fake = nullptr;
-      (void)fake;
-      if constexpr (kOut == 28) {
+    if constexpr (kOut == 28) {
 #pragma unroll
-        for (int k = 0; k < 9; ++k) P.R[k] = T(uniform_load(&s_pose[k]));
+      for (int k = 0; k < 9; ++k) P.R[k] = T(uniform_load(&s_pose[k]));
 #pragma unroll
-        for (int k = 0; k < 3; ++k) P.t[k] = T(uniform_load(&s_pose[9 + k]));
-      } else {
+      for (int k = 0; k < 3; ++k) P.t[k] = T(uniform_load(&s_pose[9 + k]));
+    } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) P.R2[k] = T(uniform_load(&s_pose[k]));
+      for (int k = 0; k < 4; ++k) P.R2[k] = T(uniform_load(&s_pose[k]));
 #pragma unroll
-        for (int k = 0; k < 2; ++k) P.t2[k] = T(uniform_load(&s_pose[9 + k]));
-      }
+      for (int k = 0; k < 2; ++k) P.t2[k] = T(uniform_load(&s_pose[9 + k]));
     }
     T acc[kOut];
 #pragma unroll
     for (int k = 0; k < kOut; ++k) acc[k] = T(0);
-    Problem::item(x, P, valid, acc);
+#pragma unroll
+    for (int j = 0; j < RI; ++j)
+      if (uint32_t(j) < J) Problem::item(x[j], P, valid[j], acc);  // grid-uniform branch
+    if constexpr (LI > 0) {
+      for (uint32_t j = RI; j < J; ++j) {
+        T xi[kF];
+#pragma unroll
+        for (int f = 0; f < kF; ++f) xi[f] = resident[(size_t(j - RI) * kF + f) * BLOCK + threadIdx.x];
+        Problem::item(xi, P, (block_base + uint64_t(j) * BLOCK + threadIdx.x) < L.n, acc);
+      }
+    }
     double dacc[kOut];
 #pragma unroll
     for (int k = 0; k < kOut; ++k) dacc[k] = double(acc[k]);
-    block_reduce_store<kOut, BLOCK>(dacc, partials + size_t(blockIdx.x) * kOut, true);  // sc1 row
-    if (threadIdx.x < kWave) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (threadIdx.x == 0) {
-      unsigned int last = 0u;
-      const unsigned int group = blockIdx.x & 7u;
-      const unsigned int group_size = (gridDim.x - group + 7u) >> 3;
-      const unsigned int n_groups = gridDim.x < 8u ? gridDim.x : 8u;
-      unsigned int* group_counter = counter + 32u * (1u + group);
-      const unsigned int t1 = __hip_atomic_fetch_add(group_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (t1 == group_size - 1u) {
-        __hip_atomic_store(group_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned int t2 = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last = (t2 == n_groups - 1u) ? 1u : 0u;
+    double* rows = partials + size_t(it & 1u) * size_t(kClusterMaxBlocks) * kOut;  // this iteration's buffer
+    NOS_RES_STAMP(0)  // item math
+    block_reduce_store<kOut, BLOCK>(dacc, rows + size_t(blockIdx.x) * kOut, true);  // sc1 row
+    NOS_RES_STAMP(1)  // block reduce + row store issued
+    if (threadIdx.x < kWave) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the row left through lanes of wave 0
+      if (threadIdx.x == 0)  // arrive (no value returned: nothing waits for this add)
+        (void)__hip_atomic_fetch_add(&ctl->arrival[group].count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // wait for everybody's arrival: lane g watches counter g
+      const unsigned int g = threadIdx.x & 7u;
+      const unsigned int g_size = (gridDim.x - g + 7u) >> 3;
+      const unsigned int target = (it + 1u) * g_size;
+      const unsigned long long deadline = wall_clock64() + kClusterTimeoutTicks;
+      int flag = 0;
+      unsigned int polls = 0;
+      for (;;) {
+        const unsigned int seen = (g < n_groups && threadIdx.x < 8u)
+                                      ? __hip_atomic_load(&ctl->arrival[g].count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                      : target;
+        if (__ballot(seen < target) == 0ull) break;  // wave-uniform
+        // the abort word and the clock are looked at on the first and then every 16th poll
+        if ((polls++ & 15u) == 0u &&
+            (__hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || wall_clock64() > deadline)) {
+          flag = 2;
+          break;
+        }
       }
-      s_last = last;
+      if (threadIdx.x == 0 && flag == 2) {
+        __hip_atomic_store(&ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_flag = 2;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // no instruction: keeps the row loads below the poll
     }
     __syncthreads();
-    wrote_last = s_last != 0u;
-    if (wrote_last) {  // block-uniform
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    NOS_RES_STAMP(2)  // drain + arrive + everybody arrived
+    if (s_flag == 2) break;  // block-uniform
+    {
+      // every workgroup adds the rows of this iteration in the same fixed order
       const int col = threadIdx.x % kCols;
       const int slice = threadIdx.x / kCols;
       constexpr int kUnroll = 16;
       double sum = 0.0;
       if (col < kOut) {
-        const double* p = partials + col;
+        const double* p = rows + col;
         for (uint32_t r = slice; r < gridDim.x; r += kUnroll * kSlices) {
           double v[kUnroll];
 #pragma unroll
@@ -1225,73 +1328,59 @@ __global__ __launch_bounds__(BLOCK) void solve_cluster_kernel(TiledLayout L, typ
         s_tot[threadIdx.x] = tot;
       }
       __syncthreads();
+      NOS_RES_STAMP(3)  // rows → sums
       if (threadIdx.x == 0) {
-        nos_host::LmState st = s_state;  // every workgroup fetched the state of this iteration together with the pose
         double out[kOut];
 #pragma unroll
         for (int k = 0; k < kOut; ++k) out[k] = s_tot[k];
-        if (cost_history != nullptr && executed < history_capacity)
+        if (blockIdx.x == 0 && cost_history != nullptr && executed < history_capacity)
           __hip_atomic_store(cost_history + executed, out[kOut - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        nos_host::LmState st = s_state;
         if constexpr (kOut == 28)
           nos_host::LmAdvance6(settings, out, &st);
         else
           nos_host::LmAdvance3(settings, out, &st);
-        state_store_sc1(lm, st);
-        __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // tickets ready for the next iteration
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // state and counter are out before the epoch
-        __hip_atomic_store(&ctl->epoch, it + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-    ++executed;
-    // everybody: wait for the epoch of this iteration, then fetch the new pose / the done flag
-    if (threadIdx.x == 0) {
-      const unsigned long long deadline = wall_clock64() + kClusterTimeoutTicks;
-      int flag = 0;
-      unsigned int polls = 0;
-      while (__hip_atomic_load(&ctl->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != it + 1u) {
-        // the abort word and the clock are looked at on the first and then every 16th poll
-        if ((polls++ & 15u) == 0u &&
-            (__hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || wall_clock64() > deadline)) {
-          __hip_atomic_store(&ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          flag = 2;
-          break;
-        }
-      }
-      if (flag == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        nos_host::LmState st;
-        state_load_sc1(lm, st);  // one batch of cache-bypassing loads: pose for everybody, the rest for the next finisher
         s_state = st;
 #pragma unroll
         for (int k = 0; k < 9; ++k) s_pose[k] = st.R[k];
 #pragma unroll
         for (int k = 0; k < 3; ++k) s_pose[9 + k] = st.t[k];
-        flag = st.done != 0 ? 1 : 0;
+        s_flag = st.done != 0 ? 1 : 0;
       }
-      s_flag = flag;
     }
-    __syncthreads();
+    ++executed;
     ++it;
+    __syncthreads();
+    NOS_RES_STAMP(4)  // LM step + barrier
   }
-  // the workgroup that finished the last iteration reports (on abort nobody does: the host sees the missing sequence word)
-  if (s_flag == 1 && (wrote_last || (executed == 0 && blockIdx.x == 0))) {
+#ifdef NOS_LM_TIMING
+  if (blockIdx.x == 0 && threadIdx.x == 0 && entry_host != nullptr)
+    for (int k = 0; k < 5; ++k)
+      __hip_atomic_store(entry_host + 50 + k, double(tq[k]) / double(executed > 0 ? executed : 1), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
+  // workgroup 0 reports (on abort nobody does: the host sees the missing sequence word)
+  if (s_flag == 1 && blockIdx.x == 0) {
     if (threadIdx.x < kOut && entry_host != nullptr && executed > 0)
       __hip_atomic_store(entry_host + kLogOut + threadIdx.x, s_tot[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (threadIdx.x == 0 && entry_host != nullptr) {
+    if (threadIdx.x == 0) {
       const nos_host::LmState st = s_state;
+      lm->st = st;
+      if (entry_host != nullptr) {
 #pragma unroll
-      for (int k = 0; k < 9; ++k)
-        __hip_atomic_store(entry_host + kLogR + k, st.R[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (int k = 0; k < 9; ++k)
+          __hip_atomic_store(entry_host + kLogR + k, st.R[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #pragma unroll
-      for (int k = 0; k < 3; ++k)
-        __hip_atomic_store(entry_host + kLogT + k, st.t[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      __hip_atomic_store(entry_host + kLogLambda, st.lambda, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      __hip_atomic_store(entry_host + kLogPrevCost, st.previous_cost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      __hip_atomic_store(entry_host + kLogCost, st.cost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      __hip_atomic_store(entry_host + kLogIteration, double(st.iteration), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      __hip_atomic_store(entry_host + kLogDone, double(st.done), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      __hip_atomic_store(entry_host + kLogOk, double(st.ok), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      __hip_atomic_store(entry_host + kLogExecuted, double(executed), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (int k = 0; k < 3; ++k)
+          __hip_atomic_store(entry_host + kLogT + k, st.t[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(entry_host + kLogLambda, st.lambda, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(entry_host + kLogPrevCost, st.previous_cost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(entry_host + kLogCost, st.cost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(entry_host + kLogIteration, double(st.iteration), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(entry_host + kLogDone, double(st.done), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(entry_host + kLogOk, double(st.ok), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(entry_host + kLogExecuted, double(executed), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
     if (threadIdx.x < kWave) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

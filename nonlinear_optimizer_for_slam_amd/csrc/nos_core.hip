@@ -190,14 +190,24 @@ int launch_by_variant(int variant, int blocks_per_cu, int num_cus, const nos::Ti
   return fail(NOS_ERR_INVALID_ARGUMENT, "bad variant");
 }
 
+// Correspondences a lane of the resident one-launch solve can hold (registers + LDS), by plane count and element type.
+size_t resident_items_per_lane(int n_fields, int dtype) {
+  if (n_fields == 15)
+    return dtype == NOS_F64 ? size_t(nos::ResidentShape<15, 8>::RI + nos::ResidentShape<15, 8>::LI)
+                            : size_t(nos::ResidentShape<15, 4>::RI + nos::ResidentShape<15, 4>::LI);
+  if (n_fields == 5)
+    return dtype == NOS_F64 ? size_t(nos::ResidentShape<5, 8>::RI + nos::ResidentShape<5, 8>::LI)
+                            : size_t(nos::ResidentShape<5, 4>::RI + nos::ResidentShape<5, 4>::LI);
+  return 1;
+}
+
 // Arguments of the single-workgroup whole-solve kernel (small problems, see nos::solve_single_block_kernel).
 struct SingleBlockArgs {
   // cluster form (one chunk per workgroup, whole loop in one launch) when cluster_blocks > 0
   int cluster_blocks = 0;
+  int items_per_lane = 1;  // correspondences every lane keeps resident (registers + LDS, nos::ResidentShape)
   double* partials = nullptr;
-  unsigned int* counter = nullptr;
   nos::ClusterCtl* ctl = nullptr;
-  unsigned int epoch_base = 0;
   nos::LmDevice* lm;
   double* history;  // device address of the pinned cost history (may be null)
   int history_capacity;
@@ -211,9 +221,22 @@ int launch_single(const nos::TiledLayout& L, const typename Problem::Params& P, 
   constexpr int kBlock = 512;
   if (L.n_padded % kBlock != 0) return fail(NOS_ERR_INVALID_ARGUMENT, "n_padded %% 512 != 0");
   if (a.cluster_blocks > 0) {
-    hipLaunchKernelGGL((nos::solve_cluster_kernel<Problem, T, kBlock>), dim3(a.cluster_blocks), dim3(kBlock), 0, stream, L, P,
-                       a.partials, a.counter, a.lm, a.ctl, a.epoch_base, a.history, a.history_capacity, a.entry, a.seq_host,
-                       a.seq);
+    using Shape = nos::ResidentShape<Problem::kFields, int(sizeof(T))>;
+    if (a.items_per_lane < 1 || a.items_per_lane > Shape::RI + Shape::LI)
+      return fail(NOS_ERR_INVALID_ARGUMENT, "resident solve: %d items per lane do not fit (%d + %d)", a.items_per_lane,
+                  Shape::RI, Shape::LI);
+    const auto kernel = nos::solve_cluster_kernel<Problem, T, kBlock, Shape::RI, Shape::LI>;
+    const size_t lds_items = a.items_per_lane > Shape::RI ? size_t(a.items_per_lane - Shape::RI) : 0;
+    const size_t dyn_bytes = lds_items * size_t(Problem::kFields) * kBlock * sizeof(T);
+    static size_t lds_granted = 0;  // per instantiation: dynamic LDS beyond the default limit must be requested once
+    if (dyn_bytes > lds_granted) {
+      const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, int(dyn_bytes));
+      if (ea != hipSuccess) return fail(NOS_ERR_HIP, "resident solve: %zu bytes of LDS refused: %s", dyn_bytes, hipGetErrorString(ea));
+      lds_granted = dyn_bytes;
+    }
+    hipLaunchKernelGGL(kernel, dim3(a.cluster_blocks), dim3(kBlock), dyn_bytes, stream, L, P, a.partials, a.lm, a.ctl,
+                       a.history, a.history_capacity, a.entry, a.seq_host, a.seq, uint32_t(a.items_per_lane));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(NOS_ERR_HIP, "cluster solve launch failed: %s", hipGetErrorString(e));
     return NOS_OK;
@@ -657,25 +680,31 @@ int lm_solve(nos_dataset* ds, const Request& rq, const nos_lm_options* opt, doub
   // Mid-size problems: one chunk per workgroup, every workgroup resident, the whole loop in one launch
   // (nos::solve_cluster_kernel).  If a wait inside times out (grid not fully resident, e.g. the GPU is shared) the
   // launch gives up and the code below runs the loop with one launch per iteration instead.
-  const size_t cluster_blocks = (sh.layout.n + 511) / 512;
+  // One 512-thread workgroup per CU at most (all of them must be resident at once); every lane keeps items_per_lane
+  // correspondences in registers + LDS.  lm_cluster: 0 off, 1 on, 2 = only the one-item-per-lane form of round 1.
+  const size_t max_blocks = std::min<size_t>(nos::kClusterMaxBlocks, size_t(slot.num_cus));
+  const size_t cluster_blocks = std::min<size_t>(max_blocks, (sh.layout.n + 511) / 512);
+  const size_t items_per_lane = cluster_blocks > 0 ? (sh.layout.n + cluster_blocks * 512 - 1) / (cluster_blocks * 512) : 0;
+  const size_t resident_capacity = ctx->settings.lm_cluster == 2 ? 1 : resident_items_per_lane(ds->n_fields, ds->dtype);
   if (ds->kind != kKindNdtIndexed && !with_comm && ctx->shm_dev == nullptr && opt->max_iterations > 0 &&
-      cluster_blocks >= 1 && cluster_blocks <= nos::kClusterMaxBlocks && cluster_blocks <= size_t(slot.num_cus) &&
+      cluster_blocks >= 1 && items_per_lane >= 1 && items_per_lane <= resident_capacity &&
       ctx->settings.lm_cluster != 0 && (opt->cost_history == nullptr || opt->max_iterations <= kHistCapacity)) {
     SingleBlockArgs cl{};
     cl.cluster_blocks = int(cluster_blocks);
+    cl.items_per_lane = int(items_per_lane);
     cl.partials = slot.partials;
-    cl.counter = slot.counter;
     cl.ctl = slot.d_cluster;
-    cl.epoch_base = slot.cluster_epoch;
     cl.lm = slot.d_lm;
     cl.history = opt->cost_history ? slot.h_hist_dev : nullptr;
     cl.history_capacity = kHistCapacity;
     cl.entry = slot.h_log_dev;
     cl.seq_host = seq_dev;
     cl.seq = ++slot.seq;
+    // arrival counters and the abort word start every launch at zero
+    NOS_HIP_CHECK(hipMemsetAsync(slot.d_cluster, 0, sizeof(nos::ClusterCtl), slot.stream));
     if (ctx->settings.debug_cluster_abort != 0) {  // test hook (nos_ctx_set_option): the launch finds `abort` already raised and gives up
-      const nos::ClusterCtl raised{slot.cluster_epoch, 1u};
-      NOS_HIP_CHECK(hipMemcpyAsync(slot.d_cluster, &raised, sizeof raised, hipMemcpyHostToDevice, slot.stream));
+      const unsigned int raised = 1u;
+      NOS_HIP_CHECK(hipMemcpyAsync(&slot.d_cluster->abort, &raised, sizeof raised, hipMemcpyHostToDevice, slot.stream));
       NOS_HIP_CHECK(hipStreamSynchronize(slot.stream));
     }
     int rows = 0;
@@ -709,7 +738,11 @@ int lm_solve(nos_dataset* ds, const Request& rq, const nos_lm_options* opt, doub
       st.done = int(e[nos::kLogDone]);
       st.ok = int(e[nos::kLogOk]);
       const int executed = int(e[nos::kLogExecuted]);
-      slot.cluster_epoch += unsigned(executed);
+#ifdef NOS_LM_TIMING
+      fprintf(stderr, "[resident-timing] %d blocks x %d items/lane, %d iterations; workgroup 0, us per iteration: item math %.2f, "
+              "block reduce %.2f, drain+arrive+wait %.2f, rows->sums %.2f, LM step+barrier %.2f\n", cl.cluster_blocks,
+              cl.items_per_lane, executed, e[50] * 0.01, e[51] * 0.01, e[52] * 0.01, e[53] * 0.01, e[54] * 0.01);
+#endif
       if (slot.prof_on && slot.prof_every == 0) slot.prof_launches += executed;  // bracket profiling counts passes over the data
       if (opt->cost_history != nullptr)
         for (int k = 0; k < executed && k < opt->max_iterations; ++k) opt->cost_history[k] = slot.h_hist[k];
@@ -728,8 +761,6 @@ int lm_solve(nos_dataset* ds, const Request& rq, const nos_lm_options* opt, doub
     }
     // gave up: put the shared words back in order and fall through to the launch-per-iteration loop from the start
     NOS_HIP_CHECK(hipMemsetAsync(slot.d_cluster, 0, sizeof(nos::ClusterCtl), slot.stream));
-    NOS_HIP_CHECK(hipMemsetAsync(slot.counter, 0, 2048, slot.stream));
-    slot.cluster_epoch = 0;
     hipLaunchKernelGGL(nos::lm_init_kernel, dim3(1), dim3(1), 0, slot.stream, slot.d_lm, init);
     NOS_HIP_CHECK(hipGetLastError());
     if (init.dof == 6)

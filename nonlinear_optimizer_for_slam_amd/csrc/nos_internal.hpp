@@ -88,8 +88,7 @@ struct DeviceSlot {
   nos::LmDevice* d_lm = nullptr;   // device-resident loop state (nos_*_solve)
   double* h_log = nullptr;         // pinned, device-mapped ring of per-iteration log entries [kLogSlots][kLogEntryDoubles]
   double* h_log_dev = nullptr;
-  nos::ClusterCtl* d_cluster = nullptr;  // epoch / abort words of the one-launch cluster solve
-  unsigned int cluster_epoch = 0;        // host copy of the epoch the device word stands at
+  nos::ClusterCtl* d_cluster = nullptr;  // abort word + arrival counters of the resident one-launch solve
   double* h_hist = nullptr;        // pinned, device-mapped cost history of the single-workgroup solve [kHistCapacity]
   double* h_hist_dev = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;

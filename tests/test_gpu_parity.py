@@ -2,9 +2,14 @@
 identical seeded inputs.  Tolerances (written here, used below):
 
   fp64 kernels vs fp64 oracle, per-iteration H/g/cost : 1e-10 scaled
-  fp32 kernels vs fp64 oracle                          : 2e-4 scaled  (reference's own fp32-vs-fp64
-                                                         gap is ~1e-5 in the final pose,
-                                                         results/maha_amd64_simple.txt:24-25)
+  fp32 kernels vs fp64 oracle, per-iteration H/g/cost : 3e-6 scaled — MEASURED worst case 1.1e-6 (NDT, exponential
+                                                         loss; 1.0e-6 of it is the rounding of the INPUTS to fp32, which
+                                                         the reference's SIMD classes share, MDM/..._analytic_simd.cc:25-27),
+                                                         reprojection 5.1e-7 (tools/measure_fp32_error.py,
+                                                         profiles/r02_fp32_error.jsonl)
+  final pose, fp32 datasets vs fp64 oracle              : 2e-7 in t, 1e-8 in q — measured 5.1e-8 / 7.4e-10 on configs[0];
+                                                         SURVEY.md §8(d) allows 2e-5 (the reference's own fp32-vs-fp64
+                                                         gap, results/maha_amd64_simple.txt:24-25)
   final pose, fp64 LM loop                              : 1e-6 (north star), expected ~1e-10
 """
 import numpy as np
@@ -16,7 +21,7 @@ from tests import helpers
 pytestmark = pytest.mark.gpu
 
 RTOL_F64 = 1e-10
-RTOL_F32 = 2e-4
+RTOL_F32 = 3e-6
 LOSSES = [None, ("exponential", 1.0, 1.0), ("huber", 1.2)]
 R_TEST = helpers.rot_xyz(0.01, -0.02, 0.05)
 T_TEST = np.array([-0.1, 0.05, 0.2])
@@ -59,7 +64,7 @@ def test_ndt3_matches_oracle(ctx, oracle, dtype, rtol, loss):
     ds.close()
 
 
-@pytest.mark.parametrize("dtype,rtol", [("f64", RTOL_F64), ("f32", 5e-3)])
+@pytest.mark.parametrize("dtype,rtol", [("f64", RTOL_F64), ("f32", 2e-6)])
 @pytest.mark.parametrize("loss", [None, ("exponential", 1.0, 1.0), ("huber", synth.REPROJ_HUBER_THRESHOLD)])
 def test_reproj_matches_oracle(ctx, oracle, dtype, rtol, loss):
     planes = synth.reproj_planes(40_003)
@@ -209,7 +214,8 @@ def test_ndt6_solve_f32_tracks_fp64_oracle(oracle):
     pose = solvers.Pose()
     assert solver.Solve(solvers.Options(), planes, pose)
     dt, dq = helpers.pose_delta(pose.R, pose.t, want["R"], want["t"])
-    assert dt < 2e-4 and dq < 2e-4, (dt, dq)
+    assert solver.report.iterations == want["iterations"]
+    assert dt < 2e-7 and dq < 1e-8, (dt, dq)
 
 
 def test_ndt3_solve_matches_oracle(oracle):
@@ -410,7 +416,7 @@ def test_cpp_class_multi_shard_and_fp32_solve_agree_with_single_shard():
     f64.SetLossFunction(loss)
     pa, pb = solvers.Pose(), solvers.Pose()
     assert f32.Solve(solvers.Options(), planes, pa) and f64.Solve(solvers.Options(), planes, pb)
-    assert np.max(np.abs(pa.t - pb.t)) < 2e-4 and np.max(np.abs(pa.R - pb.R)) < 2e-4
+    assert np.max(np.abs(pa.t - pb.t)) < 1e-6 and np.max(np.abs(pa.R - pb.R)) < 1e-6
 
 
 # ---------------------------------------------------------------- more full-size properties (BASELINE.json sizes)

@@ -1,22 +1,26 @@
 #!/bin/bash
-# Collects the rocprofv3 evidence for the headline bench on the GPU box (run via gpurun):
-#   1. kernel trace + stats of `bench.py` (the same command the driver runs, fewer steps)
-#   2. FETCH_SIZE and WRITE_SIZE in separate --pmc passes (TCC slots do not fit both), for the
-#      default fp64 geometry (8 B/lane loads) and for the 16 B/lane geometry whose FETCH_SIZE
-#      scale the microarch guide calibrates (reads exactly 1/2 of the bytes on gfx950).
-# Outputs land in gpurun_out/prof_*/ ; summarise with tools/summarize_profiles.py.
+# Collects the rocprofv3 evidence for bench.py on the GPU box (run via gpurun), one set per problem / dtype:
+#   1. kernel trace + stats of `bench.py --problem P --dtype D` (the command the driver runs, fewer steps)
+#   2. FETCH_SIZE and WRITE_SIZE in separate --pmc passes (the TCC slots do not fit both)
+#   3. one SQ pass: wave cycles, VALU-active / wait / issue-stall quad-cycles, VALU instruction count
+# usage: tools/profile_bench.sh "ndt6:f64 ndt6:f32 ndt3:f64 reproj:f64 reproj:f32"   (default: all five)
+# Outputs land in gpurun_out/prof_<P>_<D>_{stats,fetch,write,sq}/ ; summarise with tools/summarize_profiles.py <tag>.
 set -o pipefail
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=gpurun_out
-STEPS=${STEPS:-60}
-rm -rf $OUT/prof_stats $OUT/prof_fetch_v0 $OUT/prof_fetch_v3 $OUT/prof_write_v0
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -- python3 bench.py --steps $STEPS --warmup 10 --no-cpu-baseline > $OUT/prof_stats.json 2> $OUT/prof_stats.err || exit 1
-echo "stats done"
-NOS_VARIANT=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/prof_fetch_v0 -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/prof_fetch_v0.json 2> $OUT/prof_fetch_v0.err || exit 1
-echo "fetch v0 done"
-NOS_VARIANT=3 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/prof_fetch_v3 -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/prof_fetch_v3.json 2> $OUT/prof_fetch_v3.err || exit 1
-echo "fetch v3 done"
-NOS_VARIANT=0 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/prof_write_v0 -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/prof_write_v0.json 2> $OUT/prof_write_v0.err || exit 1
-echo "write v0 done"
-find $OUT/prof_stats $OUT/prof_fetch_v0 -name "*.csv" | head -20
+CASES=${1:-"ndt6:f64 ndt6:f32 ndt3:f64 reproj:f64 reproj:f32"}
+COMMON="--no-cpu-baseline --no-strong-baseline --no-cold"
+SQ="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU"
+for c in $CASES; do
+  P=${c%%:*}; D=${c##*:}
+  B=$OUT/prof_${P}_${D}
+  rm -rf ${B}_stats ${B}_fetch ${B}_write ${B}_sq
+  rocprofv3 --kernel-trace --stats --output-format csv -d ${B}_stats -- python3 bench.py --problem $P --dtype $D --steps 60 --warmup 10 --repeats 3 $COMMON > ${B}_stats.json 2> ${B}_stats.err || exit 1
+  echo "$c stats done"
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d ${B}_fetch -- python3 bench.py --problem $P --dtype $D --steps 20 --warmup 5 --repeats 1 --prewarm-ms 0 $COMMON > ${B}_fetch.json 2> ${B}_fetch.err || exit 1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d ${B}_write -- python3 bench.py --problem $P --dtype $D --steps 20 --warmup 5 --repeats 1 --prewarm-ms 0 $COMMON > ${B}_write.json 2> ${B}_write.err || exit 1
+  rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d ${B}_sq -- python3 bench.py --problem $P --dtype $D --steps 20 --warmup 5 --repeats 1 --prewarm-ms 0 $COMMON > ${B}_sq.json 2> ${B}_sq.err || exit 1
+  echo "$c counters done"
+done
+git rev-parse HEAD > $OUT/prof_commit.txt 2>/dev/null || true
