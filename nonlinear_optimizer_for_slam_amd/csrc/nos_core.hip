@@ -181,8 +181,8 @@ int launch_by_variant(int variant, int blocks_per_cu, int num_cus, const nos::Ti
       NOS_CASE(2, 1, 256, 4, 2)
       NOS_CASE(3, 2, 256, 5, 2)
       NOS_CASE(4, 2, 256, 4, 2)
-      NOS_CASE_PF(5, 2, 512, 4, 1)
-      NOS_CASE_PF(6, 4, 256, 2, 2)
+      NOS_CASE(5, 1, 1024, 4, 1)  // four waves per SIMD, 4-byte loads: loads and item math of different waves overlap
+      NOS_CASE(6, 2, 1024, 4, 1)  // the same with 8-byte loads
     }
   }
 #undef NOS_CASE

@@ -394,6 +394,37 @@ def test_eighty_million_correspondences_on_one_gpu(ctx):
     whole.close()
 
 
+def test_eighty_million_correspondences_fp64_on_one_gpu_the_strong_scaling_baseline(ctx, oracle):
+    """BASELINE.json configs[3] as ONE fp64 dataset (9.6 GB): the denominator of the 8-GPU strong-scaling claim
+    (bench.py `strong_baseline`).  The data is what the 8 ranks of `bench.py --gpus 8` hold (rank r: 10 M correspondences
+    from generator block r * 153).  Checked by additivity — the sums over the whole equal the sums of the 8 rank shards
+    (= what the all-reduce delivers) — and by the oracle on a 1 M-correspondence slice straddling two ranks."""
+    per, ranks = 10_000_000, 8
+    loss = ("exponential", 1.0, 1.0)
+    blocks_per_rank = (per + 65535) // 65536
+    big = np.empty((15, per * ranks))
+    total = np.zeros(28)
+    for r in range(ranks):
+        planes = synth.ndt_planes(per, 200_000, first_block=r * blocks_per_rank)
+        big[:, r * per:(r + 1) * per] = planes
+        ds = NdtDataset.from_planes(ctx, planes, "f64")
+        total += ds.accumulate6(R_TEST, T_TEST, loss)
+        ds.close()
+    whole = NdtDataset.from_planes(ctx, big, "f64")
+    assert len(whole) == per * ranks and whole.stream_bytes == per * ranks * 120
+    helpers.assert_normal_equations_close(whole.accumulate6(R_TEST, T_TEST, loss), total, 6, 1e-11)
+    lo, hi = 3 * per - 500_000, 3 * per + 500_000
+    sl = NdtDataset.from_planes(ctx, np.ascontiguousarray(big[:, lo:hi]), "f64")
+    helpers.assert_normal_equations_close(sl.accumulate6(R_TEST, T_TEST, loss),
+                                          oracle.ndt6_accumulate(np.ascontiguousarray(big[:, lo:hi]), R_TEST, T_TEST, loss), 6, 1e-10)
+    sl.close()
+    del big
+    # the device-resident loop on it converges to the generator's pose like the 10 M case does
+    R, t, rep = whole.solve6(np.eye(3), np.zeros(3), loss, max_iterations=40)
+    assert rep["ok"] and np.max(np.abs(t - synth.true_pose("ndt")[1])) < 5e-4
+    whole.close()
+
+
 def test_cpp_class_multi_shard_and_fp32_solve_agree_with_single_shard():
     """HipOptions.device_ids with the device listed twice (single-process fan-out inside Solve()) and dtype."""
     planes = synth.ndt_planes(80_003, 4000)

@@ -9,12 +9,14 @@ set -o pipefail
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=gpurun_out
-CASES=${1:-"ndt6:f64 ndt6:f32 ndt3:f64 reproj:f64 reproj:f32"}
+CASES=${1:-"ndt6:f64 ndt6:f32 ndt3:f64 reproj:f64 reproj:f64:stream reproj:f32:stream"}
 COMMON="--no-cpu-baseline --no-strong-baseline --no-cold"
 SQ="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU"
 for c in $CASES; do
-  P=${c%%:*}; D=${c##*:}
+  # problem:dtype[:stream]  — "stream" = NOS_LM_CLUSTER=0: the launch-per-iteration (streaming) kernel instead of the resident solve
+  P=$(echo $c | cut -d: -f1); D=$(echo $c | cut -d: -f2); M=$(echo $c | cut -d: -f3)
   B=$OUT/prof_${P}_${D}
+  if [ "$M" = "stream" ]; then export NOS_LM_CLUSTER=0; B=$OUT/prof_${P}stream_${D}; else unset NOS_LM_CLUSTER; fi
   rm -rf ${B}_stats ${B}_fetch ${B}_write ${B}_sq
   rocprofv3 --kernel-trace --stats --output-format csv -d ${B}_stats -- python3 bench.py --problem $P --dtype $D --steps 60 --warmup 10 --repeats 3 $COMMON > ${B}_stats.json 2> ${B}_stats.err || exit 1
   echo "$c stats done"

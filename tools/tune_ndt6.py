@@ -26,7 +26,7 @@ for dtype in dtypes:
         ds = NdtDataset.from_planes(ctx, planes, dtype)
         gb = ds.stream_bytes / 1e9
         for nt in (0, 1):
-            os.environ["NOS_NT"] = str(nt)
+            ctx.set_option("nt", nt)
             for variant in range(7):
                 for bpc in (0, 1, 2, 3, 4):
                     ctx.set_launch(bpc, variant)
