@@ -176,13 +176,17 @@ int launch_by_variant(int variant, int blocks_per_cu, int num_cus, const nos::Ti
     }
   } else {
     switch (variant) {
-      NOS_CASE(0, 4, 256, 2, 1)  // 16-byte loads, 4 waves per CU: best fused time (0.100 ms at 10 M) after the load-first schedule
+      // fp32 item math keeps a SIMD's VALU busy 52 % of a wave's lifetime at ONE wave per SIMD (PMC,
+      // profiles/r02_bench_ndt6_f32_summary.json).  Four waves per SIMD (variant 5) overlap loads and math better inside one
+      // launch (0.0981 → 0.0968 ms fused, profiles/r02_tune_f32.txt) but lose it again in the back-to-back device loop
+      // (0.1030 against 0.1011 ms per LM iteration), so the 16-byte-load form stays the default.
+      NOS_CASE(0, 4, 256, 2, 1)
       NOS_CASE(1, 2, 512, 4, 1)
       NOS_CASE(2, 1, 256, 4, 2)
       NOS_CASE(3, 2, 256, 5, 2)
       NOS_CASE(4, 2, 256, 4, 2)
-      NOS_CASE(5, 1, 1024, 4, 1)  // four waves per SIMD, 4-byte loads: loads and item math of different waves overlap
-      NOS_CASE(6, 2, 1024, 4, 1)  // the same with 8-byte loads
+      NOS_CASE(5, 1, 1024, 4, 1)  // four waves per SIMD, 4-byte loads
+      NOS_CASE(6, 2, 1024, 4, 1)  // four waves per SIMD, 8-byte loads
     }
   }
 #undef NOS_CASE

