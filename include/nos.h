@@ -385,7 +385,7 @@ int nos_pgo_matvec(nos_pose_graph* pg, double lambda, const double* x, double* y
  * ---- experiment knobs ----------------------------------------------------------------
  * Read from the environment once, in nos_ctx_create (NOS_SC1, NOS_NT, NOS_FUSED, NOS_LM_FUSED, NOS_LM_WINDOW,
  * NOS_LM_SINGLE, NOS_LM_CLUSTER, NOS_POOL, NOS_TILE_LOG2, NOS_PLANE_SKEW, NOS_INGEST, NOS_INGEST_THREADS,
- * NOS_INDEXED_BPC, NOS_MATCH_DENSE, NOS_PGO_HOST_SCALARS, NOS_PGO_PRECOND); afterwards only through these setters (keys =
+ * NOS_INDEXED_BPC, NOS_MATCH_DENSE, NOS_PGO_HOST_SCALARS, NOS_PGO_PRECOND, NOS_PGO_AGG); afterwards only through these setters (keys =
  * the names in lower case without the prefix, e.g. "lm_cluster"; "ingest": 0 auto, 1 pack, 2 unpack;
  * "debug_cluster_abort": test hook, makes the next one-launch solve give up and fall back).  Nothing on the solve /
  * accumulate path reads the environment. */

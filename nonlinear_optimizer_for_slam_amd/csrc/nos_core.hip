@@ -1313,6 +1313,7 @@ int nos_ctx_create(const int* device_ids, int n_devices, nos_ctx** out_ctx) {
     st.match_dense = env_int("NOS_MATCH_DENSE", st.match_dense);
     st.pgo_host_scalars = env_int("NOS_PGO_HOST_SCALARS", st.pgo_host_scalars);
     st.pgo_precond = env_int("NOS_PGO_PRECOND", st.pgo_precond);
+    st.pgo_agg = env_int("NOS_PGO_AGG", st.pgo_agg);
   }
   for (int i = 0; i < n_devices; ++i) {
     DeviceSlot& s = ctx->slots[i];
@@ -1457,7 +1458,7 @@ const OptionEntry kOptions[] = {
     {"tile_log2", &nosd::Settings::tile_log2}, {"ingest", &nosd::Settings::ingest},
     {"ingest_threads", &nosd::Settings::ingest_threads}, {"indexed_bpc", &nosd::Settings::indexed_bpc},
     {"match_dense", &nosd::Settings::match_dense}, {"pgo_host_scalars", &nosd::Settings::pgo_host_scalars},
-    {"pgo_precond", &nosd::Settings::pgo_precond}, {"debug_cluster_abort", &nosd::Settings::debug_cluster_abort},
+    {"pgo_precond", &nosd::Settings::pgo_precond}, {"pgo_agg", &nosd::Settings::pgo_agg}, {"debug_cluster_abort", &nosd::Settings::debug_cluster_abort},
 };
 }  // namespace
 

@@ -142,7 +142,8 @@ struct Settings {
   int indexed_bpc = 1;       // NOS_INDEXED_BPC
   int match_dense = 1;       // NOS_MATCH_DENSE
   int pgo_host_scalars = 0;  // NOS_PGO_HOST_SCALARS
-  int pgo_precond = 1;       // NOS_PGO_PRECOND     0 block-Jacobi only, 1 + chain / coarse correction
+  int pgo_precond = 1;       // NOS_PGO_PRECOND     0 block-Jacobi only, 1 two-level (rigid-motion coarse space)
+  int pgo_agg = 48;          // NOS_PGO_AGG         poses per aggregate of the coarse level
   int debug_cluster_abort = 0;  // test hook (no environment name): the next one-launch solve finds `abort` raised
 };
 }  // namespace nosd

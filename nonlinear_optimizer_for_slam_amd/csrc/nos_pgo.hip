@@ -2,6 +2,7 @@
 #include "nos_internal.hpp"
 
 #include "pgo_kernels.hpp"
+#include "pgo_coarse_kernels.hpp"
 
 using namespace nosd;
 
@@ -24,6 +25,11 @@ struct nos_pose_graph {
   double* h_scalars = nullptr;  // pinned [4]
   uint32_t partial_blocks = 0;
   nos::PgoView view{};
+  // coarse level of the two-level preconditioner (pgo_coarse_kernels.hpp), allocated on first use
+  uint32_t agg = 0, n_agg = 0, pcr_levels = 0;
+  double* d_coarse = nullptr;  // one allocation: L/D/U x 2, Dinv, alpha/gamma per level, rhs x 2
+  double *c_L[2] = {nullptr, nullptr}, *c_D[2] = {nullptr, nullptr}, *c_U[2] = {nullptr, nullptr};
+  double *c_Dinv = nullptr, *c_alpha = nullptr, *c_gamma = nullptr, *c_b[2] = {nullptr, nullptr};
 };
 
 namespace {
@@ -55,7 +61,7 @@ int pgo_matvec(nos_pose_graph* pg, double lambda, const double* x, double* y, do
   const uint32_t pose_blocks = (pg->n_poses + 255) / 256;
   uint32_t blocks = pose_blocks;
   hipLaunchKernelGGL(nos::pgo_matvec_pose_kernel, dim3(pose_blocks), dim3(256), 0, slot.stream, pg->view, pg->d_hdiag, lambda,
-                     x, x + N6, y, pg->d_partials);
+                     x, x + N6, y, pg->d_partials, 0u);
   if (pg->n_free_switches > 0) {  // without free switches the switch rows of x and y stay identically zero
     const uint32_t sw_blocks = (pg->n_edges + 255) / 256;
     hipLaunchKernelGGL(nos::pgo_matvec_switch_kernel, dim3(sw_blocks), dim3(256), 0, slot.stream, pg->view, pg->d_hs, lambda,
@@ -72,6 +78,97 @@ int pgo_matvec(nos_pose_graph* pg, double lambda, const double* x, double* y, do
   return NOS_OK;
 }
 
+// ---- coarse level (pgo_coarse_kernels.hpp)
+
+int pgo_coarse_alloc(nos_pose_graph* pg, uint32_t agg) {
+  if (pg->d_coarse != nullptr && pg->agg == agg) return NOS_OK;
+  if (pg->d_coarse != nullptr) {
+    (void)hipFree(pg->d_coarse);
+    pg->d_coarse = nullptr;
+  }
+  pg->agg = agg;
+  pg->n_agg = (pg->n_poses + agg - 1) / agg;
+  pg->pcr_levels = 0;
+  while ((1u << pg->pcr_levels) < pg->n_agg) ++pg->pcr_levels;
+  const size_t blk = size_t(36) * pg->n_agg, vec = size_t(6) * pg->n_agg;
+  const size_t total = 6 * blk + blk + 2 * size_t(std::max<uint32_t>(pg->pcr_levels, 1)) * blk + 2 * vec;
+  NOS_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&pg->d_coarse), total * sizeof(double)));
+  double* p = pg->d_coarse;
+  for (int k = 0; k < 2; ++k) {
+    pg->c_L[k] = p;
+    p += blk;
+    pg->c_D[k] = p;
+    p += blk;
+    pg->c_U[k] = p;
+    p += blk;
+  }
+  pg->c_Dinv = p;
+  p += blk;
+  pg->c_alpha = p;
+  p += size_t(std::max<uint32_t>(pg->pcr_levels, 1)) * blk;
+  pg->c_gamma = p;
+  p += size_t(std::max<uint32_t>(pg->pcr_levels, 1)) * blk;
+  pg->c_b[0] = p;
+  p += vec;
+  pg->c_b[1] = p;
+  return NOS_OK;
+}
+
+// Probe A_c = P^T H' P (18 masked products), then the PCR elimination.  Uses d_p / d_ap as scratch: call before the
+// CG vectors are initialised.
+int pgo_coarse_setup(nos_pose_graph* pg, double lambda, uint32_t agg) {
+  int rc = pgo_coarse_alloc(pg, agg);
+  if (rc != NOS_OK) return rc;
+  DeviceSlot& slot = pg->ctx->slots[0];
+  const uint32_t N = pg->n_poses, C = pg->n_agg;
+  const uint32_t pose_blocks = (N + 255) / 256, cblocks = (C + 127) / 128;
+  const size_t N6 = size_t(6) * N;
+  NOS_HIP_CHECK(hipMemsetAsync(pg->c_L[0], 0, size_t(3) * 36 * C * sizeof(double), slot.stream));  // L, D, U of buffer 0
+  NOS_HIP_CHECK(hipMemsetAsync(pg->d_p + N6, 0, size_t(pg->n_edges) * sizeof(double), slot.stream));  // switch part of the probe
+  for (int colour = 0; colour < 3; ++colour)
+    for (int dof = 0; dof < 6; ++dof) {
+      hipLaunchKernelGGL(nos::pgo_coarse_probe_kernel, dim3(pose_blocks), dim3(256), 0, slot.stream, pg->view, agg, colour, dof,
+                         pg->d_p);
+      hipLaunchKernelGGL(nos::pgo_matvec_pose_kernel, dim3(pose_blocks), dim3(256), 0, slot.stream, pg->view, pg->d_hdiag,
+                         lambda, pg->d_p, pg->d_p + N6, pg->d_ap, pg->d_partials, agg);
+      hipLaunchKernelGGL(nos::pgo_coarse_restrict_kernel, dim3(cblocks), dim3(128), 0, slot.stream, pg->view, agg, C, pg->d_ap,
+                         pg->c_b[0]);
+      hipLaunchKernelGGL(nos::pgo_coarse_scatter_kernel, dim3(cblocks), dim3(128), 0, slot.stream, C, colour, dof, pg->c_b[0],
+                         pg->c_L[0], pg->c_D[0], pg->c_U[0]);
+    }
+  hipLaunchKernelGGL(nos::pgo_coarse_symmetrize_kernel, dim3(cblocks), dim3(128), 0, slot.stream, C, pg->c_L[0], pg->c_D[0],
+                     pg->c_U[0]);
+  int cur = 0;
+  for (uint32_t lvl = 0; lvl < pg->pcr_levels; ++lvl) {
+    hipLaunchKernelGGL(nos::pgo_pcr_setup_kernel, dim3(cblocks), dim3(128), 0, slot.stream, C, 1u << lvl, pg->c_L[cur],
+                       pg->c_D[cur], pg->c_U[cur], pg->c_L[1 - cur], pg->c_D[1 - cur], pg->c_U[1 - cur],
+                       pg->c_alpha + size_t(lvl) * 36 * C, pg->c_gamma + size_t(lvl) * 36 * C);
+    cur = 1 - cur;
+  }
+  hipLaunchKernelGGL(nos::pgo_pcr_finish_kernel, dim3(cblocks), dim3(128), 0, slot.stream, C, pg->c_D[cur], pg->c_Dinv);
+  NOS_HIP_CHECK(hipGetLastError());
+  return NOS_OK;
+}
+
+// xc = A_c^-1 P^T r  →  returns the buffer holding xc.
+int pgo_coarse_apply(nos_pose_graph* pg, const double* r, const double** xc) {
+  DeviceSlot& slot = pg->ctx->slots[0];
+  const uint32_t C = pg->n_agg, cblocks = (C + 127) / 128;
+  hipLaunchKernelGGL(nos::pgo_coarse_restrict_kernel, dim3(cblocks), dim3(128), 0, slot.stream, pg->view, pg->agg, C, r,
+                     pg->c_b[0]);
+  int cur = 0;
+  for (uint32_t lvl = 0; lvl < pg->pcr_levels; ++lvl) {
+    hipLaunchKernelGGL(nos::pgo_pcr_apply_kernel, dim3(cblocks), dim3(128), 0, slot.stream, C, 1u << lvl,
+                       pg->c_alpha + size_t(lvl) * 36 * C, pg->c_gamma + size_t(lvl) * 36 * C, pg->c_b[cur], pg->c_b[1 - cur]);
+    cur = 1 - cur;
+  }
+  hipLaunchKernelGGL(nos::pgo_pcr_solve_kernel, dim3(cblocks), dim3(128), 0, slot.stream, C, pg->c_Dinv, pg->c_b[cur],
+                     pg->c_b[1 - cur]);
+  NOS_HIP_CHECK(hipGetLastError());
+  *xc = pg->c_b[1 - cur];
+  return NOS_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -81,7 +178,7 @@ int nos_pgo_destroy(nos_pose_graph* pg) {
   if (!pg) return NOS_OK;
   void* bufs[] = {pg->d_pose, pg->d_ref, pg->d_qry, pg->d_edge, pg->d_adj_nbr, pg->d_sw_free, pg->d_fixed, pg->d_adj_off,
                   pg->d_adj, pg->d_hdiag, pg->d_minv, pg->d_hs, pg->d_grad, pg->d_x, pg->d_r, pg->d_z, pg->d_p,
-                  pg->d_ap, pg->d_partials, pg->d_scalars};
+                  pg->d_ap, pg->d_partials, pg->d_scalars, pg->d_coarse};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (pg->h_scalars) (void)hipHostFree(pg->h_scalars);
@@ -238,14 +335,33 @@ int nos_pgo_solve(nos_pose_graph* pg, double lambda, int max_iterations, double 
   const uint32_t pblocks = (pg->n_poses + active_edges + 255) / 256;
   hipLaunchKernelGGL(nos::pgo_precond_kernel, dim3((pg->n_poses + 255) / 256), dim3(256), 0, slot.stream, pg->d_hdiag,
                      lambda, pg->n_poses, pg->d_minv);
+  // two-level preconditioner: rigid-motion coarse space over aggregates of consecutive poses (pgo_coarse_kernels.hpp);
+  // worth its set-up (18 products) from a few aggregates on
+  const uint32_t agg = uint32_t(std::max(2, pg->ctx->settings.pgo_agg));
+  const bool two_level = pg->ctx->settings.pgo_precond != 0 && pg->n_poses >= 4 * agg;
+  if (two_level) {
+    const int rcs = pgo_coarse_setup(pg, lambda, agg);
+    if (rcs != NOS_OK) return rcs;
+  }
+  auto apply_precond = [&]() -> int {
+    const double* xc = nullptr;
+    if (two_level) {
+      const int rca = pgo_coarse_apply(pg, pg->d_r, &xc);
+      if (rca != NOS_OK) return rca;
+    }
+    hipLaunchKernelGGL(nos::pgo_apply_precond_kernel, dim3(pblocks), dim3(256), 0, slot.stream, pg->d_minv, pg->d_hs, lambda,
+                       pg->n_poses, active_edges, pg->d_r, pg->d_r + N6, pg->d_z, pg->d_z + N6, pg->d_partials, pg->d_pose,
+                       pg->d_fixed, xc, agg);
+    return NOS_OK;
+  };
   // x = 0, r = -g
   NOS_HIP_CHECK(hipMemsetAsync(pg->d_x, 0, n * sizeof(double), slot.stream));
   NOS_HIP_CHECK(hipMemsetAsync(pg->d_r, 0, n * sizeof(double), slot.stream));
   hipLaunchKernelGGL(nos::pgo_cg_update_kernel, dim3(vblocks), dim3(256), 0, slot.stream, n, 1.0, pg->d_x, pg->d_grad,
                      pg->d_p /*scratch x: untouched since alpha*p with p = d_x = 0*/, pg->d_r);
   auto precond = [&](double* rz, double* rr) -> int {
-    hipLaunchKernelGGL(nos::pgo_apply_precond_kernel, dim3(pblocks), dim3(256), 0, slot.stream, pg->d_minv, pg->d_hs, lambda,
-                       pg->n_poses, active_edges, pg->d_r, pg->d_r + N6, pg->d_z, pg->d_z + N6, pg->d_partials);
+    const int rcp = apply_precond();
+    if (rcp != NOS_OK) return rcp;
     hipLaunchKernelGGL(nos::pgo_sum_partials_kernel, dim3(1), dim3(1024), 0, slot.stream, pg->d_partials, pblocks, 2,
                        pg->d_scalars);
     NOS_HIP_CHECK(hipGetLastError());
@@ -284,8 +400,8 @@ int nos_pgo_solve(nos_pose_graph* pg, double lambda, int max_iterations, double 
         hipLaunchKernelGGL(nos::pgo_cg_alpha_kernel, dim3(1), dim3(1), 0, slot.stream, pg->d_scalars);
         hipLaunchKernelGGL(nos::pgo_cg_update_dev_kernel, dim3(vblocks), dim3(256), 0, slot.stream, n, pg->d_scalars, pg->d_p,
                            pg->d_ap, pg->d_x, pg->d_r);
-        hipLaunchKernelGGL(nos::pgo_apply_precond_kernel, dim3(pblocks), dim3(256), 0, slot.stream, pg->d_minv, pg->d_hs, lambda,
-                           pg->n_poses, active_edges, pg->d_r, pg->d_r + N6, pg->d_z, pg->d_z + N6, pg->d_partials);
+        rc = apply_precond();
+        if (rc != NOS_OK) return rc;
         hipLaunchKernelGGL(nos::pgo_sum_partials_kernel, dim3(1), dim3(1024), 0, slot.stream, pg->d_partials, pblocks, 2,
                            pg->d_scalars);
         hipLaunchKernelGGL(nos::pgo_cg_beta_kernel, dim3(1), dim3(1), 0, slot.stream, pg->d_scalars);

@@ -1,0 +1,348 @@
+// pgo_coarse_kernels.hpp — coarse level of the two-level preconditioner of the pose-graph PCG (configs[4]).
+//
+// Why: a SLAM trajectory is a long chain with local extra constraints; block-Jacobi PCG on its normal equations needs a
+// number of iterations that grows with the length of the chain (the slow modes are "bendings" of the whole trajectory): at
+// 1 M poses the round-1 solver ran into its 300-iteration cap from the third LM iteration on.  The coarse space below makes
+// the iteration count independent of the length (measured on the CPU prototype: 2 080 → 66 iterations at 6 k and at 24 k
+// poses, λ = 1e-6; tools/measure_pgo.py for the GPU).
+//
+// Coarse space: the poses are cut into aggregates of `agg` consecutive indices (trajectory order).  Aggregate I carries six
+// unknowns (a, θ): a translation and a WORLD-frame rotation about its first pose's position c_I — a rigid motion of the
+// whole aggregate.  Under the solvers' update rule (p ← p + δp, q ← q ⊗ Exp(δω), δω in the pose's own frame) pose i of the
+// aggregate moves by
+//        δp_i = a + θ x (p_i − c_I),   δω_i = R_iᵀ θ           i.e.  δx_i = B_i (a, θ),  B_i = [ I  −[p_i − c_I]x ; 0  R_iᵀ ]
+// (fixed poses: B_i = 0).  Prolongation P stacks the B_i; the preconditioner is additive,
+//        M⁻¹ r = blockdiag(H_ii)⁻¹ r  +  P A_c⁻¹ Pᵀ r,        A_c = Pᵀ H' P,
+// both terms symmetric positive definite.  H' is the damped normal matrix with the coupling of constraints that span more
+// than neighbouring aggregates dropped (their diagonal blocks stay): H' is then block tridiagonal over aggregates whatever
+// loop closures the graph has, and within a factor two of H on those constraints.
+//
+// A_c is never assembled from blocks — the library stores nothing of H but its diagonal: it is PROBED.  Aggregates are
+// three-coloured (I mod 3); for each colour and each of the six coarse unknowns one masked product y = H' P e is formed with
+// the matrix-free sweep of pgo_kernels.hpp and restricted (Pᵀ y): 18 products per LM iteration give all three block
+// diagonals.  The block-tridiagonal system is solved by parallel cyclic reduction (PCR): ⌈log2 n_c⌉ levels, one thread per
+// aggregate per level, the elimination factors of every level are kept so that applying A_c⁻¹ to a right-hand side costs
+// one small kernel per level.  Everything runs in a fixed order: results are bit-reproducible.
+#pragma once
+
+#include "pgo_kernels.hpp"
+
+namespace nos {
+
+// ---- 6x6 helpers (row-major, in registers)
+
+__device__ __forceinline__ void m6_load(const double* __restrict__ p, double (&A)[36]) {
+#pragma unroll
+  for (int k = 0; k < 36; ++k) A[k] = p[k];
+}
+__device__ __forceinline__ void m6_store(double* __restrict__ p, const double (&A)[36]) {
+#pragma unroll
+  for (int k = 0; k < 36; ++k) p[k] = A[k];
+}
+// C = A B
+__device__ __forceinline__ void m6_mul(const double (&A)[36], const double (&B)[36], double (&C)[36]) {
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      double v = 0.0;
+#pragma unroll
+      for (int m = 0; m < 6; ++m) v = fma(A[6 * r + m], B[6 * m + c], v);
+      C[6 * r + c] = v;
+    }
+}
+// y += A x
+__device__ __forceinline__ void m6_mulvec_add(const double (&A)[36], const double (&x)[6], double (&y)[6]) {
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    double v = y[r];
+#pragma unroll
+    for (int m = 0; m < 6; ++m) v = fma(A[6 * r + m], x[m], v);
+    y[r] = v;
+  }
+}
+// Inverse of a symmetric positive definite 6x6 (Cholesky; pivots floored so that an empty aggregate cannot poison the
+// recurrence).  Only the upper triangle of A is read.
+__device__ __forceinline__ void m6_spd_inverse(const double (&A)[36], double (&Ai)[36]) {
+  double L[6][6], Li[6][6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      L[r][c] = 0.0;
+      Li[r][c] = 0.0;
+    }
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    double d = A[6 * j + j];
+#pragma unroll
+    for (int m = 0; m < 6; ++m)
+      if (m < j) d -= L[j][m] * L[j][m];
+    d = d > 1e-300 ? d : 1e-300;
+    const double lj = sqrt(d);
+    L[j][j] = lj;
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+      if (r > j) {
+        double v = A[6 * j + r];  // upper triangle: A(j, r) = A(r, j)
+#pragma unroll
+        for (int m = 0; m < 6; ++m)
+          if (m < j) v -= L[r][m] * L[j][m];
+        L[r][j] = v / lj;
+      }
+  }
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    Li[c][c] = 1.0 / L[c][c];
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+      if (r > c) {
+        double v = 0.0;
+#pragma unroll
+        for (int m = 0; m < 6; ++m)
+          if (m >= c && m < r) v -= L[r][m] * Li[m][c];
+        Li[r][c] = v / L[r][r];
+      }
+  }
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      double v = 0.0;
+#pragma unroll
+      for (int m = 0; m < 6; ++m)
+        if (m >= r && m >= c) v += Li[m][r] * Li[m][c];
+      Ai[6 * r + c] = v;
+    }
+}
+
+// B_i of the header comment for pose i of aggregate I (c = position of the aggregate's first pose).
+__device__ __forceinline__ void coarse_basis(const PgoView& G, uint32_t i, uint32_t agg, double (&B)[36]) {
+  double pi[8], pc[8];
+  load_record(G.pose, i, pi);
+  load_record(G.pose, size_t(i / agg) * agg, pc);
+  double R[9];
+  qrot_matrix(Quat4{pi[3], pi[4], pi[5], pi[6]}, R);
+  const double d[3] = {pi[0] - pc[0], pi[1] - pc[1], pi[2] - pc[2]};
+#pragma unroll
+  for (int k = 0; k < 36; ++k) B[k] = 0.0;
+  B[0] = B[7] = B[14] = 1.0;
+  // −[d]x = [0 dz −dy; −dz 0 dx; dy −dx 0]
+  B[4] = d[2];
+  B[5] = -d[1];
+  B[9] = -d[2];
+  B[11] = d[0];
+  B[15] = d[1];
+  B[16] = -d[0];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) B[6 * (3 + r) + 3 + c] = R[3 * c + r];  // R_iᵀ
+}
+
+// Probe vector: x_i = column `dof` of B_i for the free poses of the aggregates with I mod 3 == colour, 0 elsewhere.
+__global__ __launch_bounds__(256) void pgo_coarse_probe_kernel(PgoView G, uint32_t agg, int colour, int dof,
+                                                               double* __restrict__ x) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= G.n_poses) return;
+  double out[6] = {0, 0, 0, 0, 0, 0};
+  if (!G.fixed[i] && int((i / agg) % 3u) == colour) {
+    double B[36];
+    coarse_basis(G, i, agg, B);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) out[r] = B[6 * r + dof];
+  }
+#pragma unroll
+  for (int r = 0; r < 6; ++r) x[size_t(6) * i + r] = out[r];
+}
+
+// Restriction rc_J = Σ_{i in J} B_iᵀ y_i, one thread per aggregate, poses in index order.
+__global__ __launch_bounds__(128) void pgo_coarse_restrict_kernel(PgoView G, uint32_t agg, uint32_t n_agg,
+                                                                  const double* __restrict__ y, double* __restrict__ rc) {
+  const uint32_t J = blockIdx.x * 128 + threadIdx.x;
+  if (J >= n_agg) return;
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+  const uint32_t lo = J * agg, hi = (lo + agg < G.n_poses) ? lo + agg : G.n_poses;
+  for (uint32_t i = lo; i < hi; ++i) {
+    if (G.fixed[i]) continue;
+    double B[36], yi[6];
+    coarse_basis(G, i, agg, B);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) yi[r] = y[size_t(6) * i + r];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      double v = acc[c];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) v = fma(B[6 * r + c], yi[r], v);
+      acc[c] = v;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 6; ++c) rc[size_t(6) * J + c] = acc[c];
+}
+
+// One probing product gives column `dof` of the blocks A_c(J, I) with I the aggregate of colour `colour` among J−1, J, J+1.
+// L / D / U: [n_agg][36] row-major blocks A_c(J, J−1), A_c(J, J), A_c(J, J+1).
+__global__ __launch_bounds__(128) void pgo_coarse_scatter_kernel(uint32_t n_agg, int colour, int dof,
+                                                                 const double* __restrict__ rc, double* __restrict__ L,
+                                                                 double* __restrict__ D, double* __restrict__ U) {
+  const uint32_t J = blockIdx.x * 128 + threadIdx.x;
+  if (J >= n_agg) return;
+  const int cj = int(J % 3u);
+  double* dst = cj == colour ? D : ((cj + 1) % 3 == colour ? U : L);  // colour of J+1 is cj+1, of J−1 is cj+2 (mod 3)
+  if ((dst == U && J + 1 >= n_agg) || (dst == L && J == 0)) return;
+#pragma unroll
+  for (int r = 0; r < 6; ++r) dst[size_t(36) * J + 6 * r + dof] = rc[size_t(6) * J + r];
+}
+
+// Make the probed operator exactly symmetric (D ← (D + Dᵀ)/2, L_J ← (L_J + U_{J−1}ᵀ)/2, U_{J−1} ← L_Jᵀ) and give
+// aggregates without a free pose an identity block.
+__global__ __launch_bounds__(128) void pgo_coarse_symmetrize_kernel(uint32_t n_agg, double* __restrict__ L,
+                                                                    double* __restrict__ D, double* __restrict__ U) {
+  const uint32_t J = blockIdx.x * 128 + threadIdx.x;
+  if (J >= n_agg) return;
+  double d[36];
+  m6_load(D + size_t(36) * J, d);
+  bool empty = true;
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int c = r; c < 6; ++c) {
+      const double v = 0.5 * (d[6 * r + c] + d[6 * c + r]);
+      d[6 * r + c] = v;
+      d[6 * c + r] = v;
+      empty = empty && v == 0.0;
+    }
+  if (empty) {
+#pragma unroll
+    for (int r = 0; r < 6; ++r) d[7 * r] = 1.0;
+  }
+  m6_store(D + size_t(36) * J, d);
+  if (J > 0) {
+    double l[36], u[36];
+    m6_load(L + size_t(36) * J, l);
+    m6_load(U + size_t(36) * (J - 1), u);
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const double v = 0.5 * (l[6 * r + c] + u[6 * c + r]);
+        L[size_t(36) * J + 6 * r + c] = v;
+        U[size_t(36) * (J - 1) + 6 * c + r] = v;
+      }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 36; ++k) L[k] = 0.0;
+  }
+  if (J + 1 == n_agg) {
+#pragma unroll
+    for (int k = 0; k < 36; ++k) U[size_t(36) * J + k] = 0.0;
+  }
+}
+
+// One level of parallel cyclic reduction with stride d: row J is combined with rows J − d and J + d,
+//   alpha = −L_J D_{J−d}⁻¹,  gamma = −U_J D_{J+d}⁻¹,
+//   L'_J = alpha L_{J−d},  D'_J = D_J + alpha U_{J−d} + gamma L_{J+d},  U'_J = gamma U_{J+d};
+// alpha / gamma are kept (per level) for the right-hand sides.  in / out are different buffers.
+__global__ __launch_bounds__(128) void pgo_pcr_setup_kernel(uint32_t n_agg, uint32_t d, const double* __restrict__ Lin,
+                                                            const double* __restrict__ Din, const double* __restrict__ Uin,
+                                                            double* __restrict__ Lout, double* __restrict__ Dout,
+                                                            double* __restrict__ Uout, double* __restrict__ alpha,
+                                                            double* __restrict__ gamma) {
+  const uint32_t J = blockIdx.x * 128 + threadIdx.x;
+  if (J >= n_agg) return;
+  double Dn[36], Ln[36], Un[36], a[36], g[36], t[36], inv[36], blk[36];
+  m6_load(Din + size_t(36) * J, Dn);
+#pragma unroll
+  for (int k = 0; k < 36; ++k) {
+    Ln[k] = 0.0;
+    Un[k] = 0.0;
+    a[k] = 0.0;
+    g[k] = 0.0;
+  }
+  if (J >= d) {
+    m6_load(Din + size_t(36) * (J - d), blk);
+    m6_spd_inverse(blk, inv);
+    m6_load(Lin + size_t(36) * J, blk);
+    m6_mul(blk, inv, a);
+#pragma unroll
+    for (int k = 0; k < 36; ++k) a[k] = -a[k];
+    m6_load(Uin + size_t(36) * (J - d), blk);
+    m6_mul(a, blk, t);
+#pragma unroll
+    for (int k = 0; k < 36; ++k) Dn[k] += t[k];
+    m6_load(Lin + size_t(36) * (J - d), blk);
+    m6_mul(a, blk, Ln);
+  }
+  if (J + d < n_agg) {
+    m6_load(Din + size_t(36) * (J + d), blk);
+    m6_spd_inverse(blk, inv);
+    m6_load(Uin + size_t(36) * J, blk);
+    m6_mul(blk, inv, g);
+#pragma unroll
+    for (int k = 0; k < 36; ++k) g[k] = -g[k];
+    m6_load(Lin + size_t(36) * (J + d), blk);
+    m6_mul(g, blk, t);
+#pragma unroll
+    for (int k = 0; k < 36; ++k) Dn[k] += t[k];
+    m6_load(Uin + size_t(36) * (J + d), blk);
+    m6_mul(g, blk, Un);
+  }
+  m6_store(Lout + size_t(36) * J, Ln);
+  m6_store(Dout + size_t(36) * J, Dn);
+  m6_store(Uout + size_t(36) * J, Un);
+  m6_store(alpha + size_t(36) * J, a);
+  m6_store(gamma + size_t(36) * J, g);
+}
+
+// Inverse of the decoupled diagonal blocks after the last level.
+__global__ __launch_bounds__(128) void pgo_pcr_finish_kernel(uint32_t n_agg, const double* __restrict__ D,
+                                                             double* __restrict__ Dinv) {
+  const uint32_t J = blockIdx.x * 128 + threadIdx.x;
+  if (J >= n_agg) return;
+  double d[36], inv[36];
+  m6_load(D + size_t(36) * J, d);
+  m6_spd_inverse(d, inv);
+  m6_store(Dinv + size_t(36) * J, inv);
+}
+
+// Right-hand side of one level: b'_J = b_J + alpha_J b_{J−d} + gamma_J b_{J+d}.
+__global__ __launch_bounds__(128) void pgo_pcr_apply_kernel(uint32_t n_agg, uint32_t d, const double* __restrict__ alpha,
+                                                            const double* __restrict__ gamma, const double* __restrict__ bin,
+                                                            double* __restrict__ bout) {
+  const uint32_t J = blockIdx.x * 128 + threadIdx.x;
+  if (J >= n_agg) return;
+  double b[6], x[6], m[36];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) b[k] = bin[size_t(6) * J + k];
+  if (J >= d) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) x[k] = bin[size_t(6) * (J - d) + k];
+    m6_load(alpha + size_t(36) * J, m);
+    m6_mulvec_add(m, x, b);
+  }
+  if (J + d < n_agg) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) x[k] = bin[size_t(6) * (J + d) + k];
+    m6_load(gamma + size_t(36) * J, m);
+    m6_mulvec_add(m, x, b);
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) bout[size_t(6) * J + k] = b[k];
+}
+
+// x_J = D_J⁻¹ b_J
+__global__ __launch_bounds__(128) void pgo_pcr_solve_kernel(uint32_t n_agg, const double* __restrict__ Dinv,
+                                                            const double* __restrict__ b, double* __restrict__ x) {
+  const uint32_t J = blockIdx.x * 128 + threadIdx.x;
+  if (J >= n_agg) return;
+  double m[36], bi[6], xi[6] = {0, 0, 0, 0, 0, 0};
+  m6_load(Dinv + size_t(36) * J, m);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) bi[k] = b[size_t(6) * J + k];
+  m6_mulvec_add(m, bi, xi);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) x[size_t(6) * J + k] = xi[k];
+}
+
+}  // namespace nos

@@ -270,7 +270,10 @@ __global__ __launch_bounds__(256) void pgo_matvec_pose_kernel(PgoView G, const d
                                                               double lambda, const double* __restrict__ x,
                                                               const double* __restrict__ xs,
                                                               double* __restrict__ y,
-                                                              double* __restrict__ dot_partials) {
+                                                              double* __restrict__ dot_partials,
+                                                              uint32_t mask_agg = 0) {
+  // mask_agg != 0: the coupling of constraints whose ends lie more than one aggregate (of mask_agg consecutive poses)
+  // apart is dropped, their diagonal part stays — the operator the coarse level is probed with (pgo_coarse_kernels.hpp)
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   const size_t N = G.n_poses;
   double xy = 0.0;
@@ -295,7 +298,11 @@ __global__ __launch_bounds__(256) void pgo_matvec_pose_kernel(PgoView G, const d
     EdgeTerms T;
     const double s = edge_terms(G, e, role == 0 ? i : j, role == 0 ? j : i, T);
     double xj[6], v[6], vj[6];
-    const bool jfixed = G.fixed[j] != 0;
+    bool jfixed = G.fixed[j] != 0;
+    if (mask_agg != 0) {
+      const uint32_t ai = i / mask_agg, aj = j / mask_agg;
+      jfixed = jfixed || ai > aj + 1u || aj > ai + 1u;
+    }
 #pragma unroll
     for (int k = 0; k < 6; ++k) xj[k] = jfixed ? 0.0 : x[size_t(6) * j + k];
     apply_J(T, role, xi, v);
@@ -444,7 +451,11 @@ __global__ __launch_bounds__(256) void pgo_apply_precond_kernel(const double* __
                                                                 const double* __restrict__ r,
                                                                 const double* __restrict__ rs, double* __restrict__ z,
                                                                 double* __restrict__ zs,
-                                                                double* __restrict__ partials) {
+                                                                double* __restrict__ partials,
+                                                                const double* __restrict__ pose_rec = nullptr,
+                                                                const uint8_t* __restrict__ fixed = nullptr,
+                                                                const double* __restrict__ xc = nullptr, uint32_t agg = 0) {
+  // xc != nullptr: two-level form, z_i = M_ii^-1 r_i + B_i xc[aggregate of i] (coarse correction, pgo_coarse_kernels.hpp)
   const uint32_t t = blockIdx.x * 256 + threadIdx.x;
   double rz = 0.0, rr = 0.0;
   if (t < n_poses) {
@@ -460,9 +471,25 @@ __global__ __launch_bounds__(256) void pgo_apply_precond_kernel(const double* __
         M[a][b] = v;
         M[b][a] = v;
       }
+    double corr[6] = {0, 0, 0, 0, 0, 0};
+    if (xc != nullptr && !fixed[t]) {
+      // B_t = [ I  -[p_t - c]x ; 0  R_t^T ] applied to the aggregate's (a, theta)
+      double pi[8], pc[8], R[9], xa[6];
+      load_record(pose_rec, t, pi);
+      load_record(pose_rec, size_t(t / agg) * agg, pc);
+      qrot_matrix(Quat4{pi[3], pi[4], pi[5], pi[6]}, R);
+#pragma unroll
+      for (int a = 0; a < 6; ++a) xa[a] = xc[size_t(6) * (t / agg) + a];
+      const double d[3] = {pi[0] - pc[0], pi[1] - pc[1], pi[2] - pc[2]};
+      corr[0] = xa[0] + (xa[4] * d[2] - xa[5] * d[1]);  // a + theta x d
+      corr[1] = xa[1] + (xa[5] * d[0] - xa[3] * d[2]);
+      corr[2] = xa[2] + (xa[3] * d[1] - xa[4] * d[0]);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) corr[3 + a] = R[a] * xa[3] + R[3 + a] * xa[4] + R[6 + a] * xa[5];  // R^T theta
+    }
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
-      double v = 0.0;
+      double v = corr[a];
 #pragma unroll
       for (int b = 0; b < 6; ++b) v += M[a][b] * ri[b];
       z[size_t(6) * t + a] = v;

@@ -208,6 +208,55 @@ def test_large_graph_generator_and_gpu_loop(ctx):
 
 
 @pytest.mark.gpu
+def test_configs4_full_size_every_pcg_solve_converges_and_the_loop_descends(ctx):
+    """BASELINE.json configs[4] at FULL size: 1 M poses / ~4 M relative-pose constraints.  With the two-level
+    preconditioner (rigid-motion coarse space over aggregates of consecutive poses + block-Jacobi, csrc/pgo_coarse_kernels.hpp)
+    EVERY linear solve of the LM loop reaches 1e-6 well inside the 300-iteration cap (round 1's block-Jacobi PCG ran into
+    the cap from the third LM iteration on), the cost never increases and the gradient norm falls by more than 1e-3."""
+    from nonlinear_optimizer_for_slam_amd import pgo, synth
+    d = synth.pose_graph(1_000_000, 3)
+    assert 3_900_000 < d["ref"].size < 4_100_000
+    g = pgo.PoseGraph(ctx, d["init"], d["ref"], d["qry"], d["meas"], None, None, d["fixed"])
+    it, hist = g.optimize(max_iterations=6, gradient_tolerance=1e-9, parameter_tolerance=1e-9, pcg_iterations=300,
+                          pcg_tolerance=1e-6)
+    costs = [h[0] for h in hist]
+    assert all(h[3] < 200 and h[4] <= 1e-6 for h in hist), [(h[3], h[4]) for h in hist]   # iterations, relative residual
+    assert all(b <= a * (1 + 1e-12) for a, b in zip(costs, costs[1:])), costs
+    c_end, g_end = g.linearize()
+    assert c_end <= costs[-1] and c_end < 3e-3 * costs[0] and g_end < 1e-3 * hist[0][1], (c_end, g_end, hist[0])
+    # the same linearisation through round 1's preconditioner alone: does not get there
+    with ctx.options(pgo_precond=0):
+        it_bj, res_bj, _ = g.solve(1e-6, 300, 1e-6)
+    it_2l, res_2l, _ = g.solve(1e-6, 300, 1e-6)
+    assert it_bj == 300 and res_bj > 1e-6 and it_2l < 200 and res_2l <= 1e-6, (it_bj, res_bj, it_2l, res_2l)
+    g.close()
+
+
+@pytest.mark.gpu
+def test_two_level_preconditioner_is_a_preconditioner_not_a_different_solve(ctx):
+    """Same converged step with and without the coarse level (it changes the iteration count, not the answer), on a graph
+    with loop closures that span many aggregates (their coupling is dropped from the coarse operator only)."""
+    d = op.random_graph(3000, 3, seed=4)
+    rng = np.random.default_rng(0)
+    extra_ref = rng.integers(0, 1500, 40)
+    extra_qry = extra_ref + rng.integers(800, 1400, 40)       # long loop closures
+    ref = np.concatenate([d["ref"], extra_ref]).astype(np.int32)
+    qry = np.concatenate([d["qry"], extra_qry]).astype(np.int32)
+    meas = np.concatenate([d["meas"], d["meas"][:40]])        # inconsistent on purpose: only the linear algebra matters
+    from nonlinear_optimizer_for_slam_amd import pgo
+    g = pgo.PoseGraph(ctx, d["init"], ref, qry, meas, None, None, d["fixed"])
+    g.linearize()
+    it2, res2, _ = g.solve(1e-3, 3000, 1e-12)
+    x2 = g.vector("step").copy()
+    with ctx.options(pgo_precond=0):
+        it1, res1, _ = g.solve(1e-3, 3000, 1e-12)
+    x1 = g.vector("step").copy()
+    assert res1 <= 1e-12 and res2 <= 1e-12 and it2 < it1, (it1, res1, it2, res2)
+    np.testing.assert_allclose(x2, x1, rtol=0, atol=1e-6 * np.max(np.abs(x1)))
+    g.close()
+
+
+@pytest.mark.gpu
 def test_pcg_with_device_resident_scalars_equals_host_scalar_pcg(ctx):
     """The CG scalars (alpha, beta, r.z) live on the device by default and the host looks at |r| every 8th iteration;
     the context option pgo_host_scalars = 1 restores the per-iteration readback.  Same arithmetic: at a fixed iteration count (a multiple

@@ -18,6 +18,13 @@ x = np.random.default_rng(0).normal(size=g.n_unknowns)
 for iters in (50, 200):
     t0 = time.perf_counter(); it, res, step = g.solve(1e-3, iters, 0.0); dt = time.perf_counter() - t0
     print("pcg: %d iterations in %.2f ms = %.3f ms/iteration, rel residual %.3e" % (it, 1e3 * dt, 1e3 * dt / max(it, 1), res), flush=True)
+for mode in (1, 0):  # PCG on the same linearisation: two-level preconditioner, then round 1's block-Jacobi
+    ctx.set_option("pgo_precond", mode)
+    for lam in (1e-3, 1e-6):
+        t0 = time.perf_counter(); it, res, step = g.solve(lam, 300, 1e-6); dt = time.perf_counter() - t0
+        print("pcg (%s, lambda %g): %d iterations in %.2f ms = %.3f ms/iteration, rel residual %.3e"
+              % ("two-level" if mode else "block-Jacobi", lam, it, 1e3 * dt, 1e3 * dt / max(it, 1), res), flush=True)
+ctx.set_option("pgo_precond", 1)
 t0 = time.perf_counter()
 it, hist = g.optimize(max_iterations=10, gradient_tolerance=1e-6, parameter_tolerance=1e-6, pcg_iterations=300, pcg_tolerance=1e-6)
 dt = time.perf_counter() - t0
