@@ -131,8 +131,8 @@ int pgo_coarse_setup(nos_pose_graph* pg, double lambda, uint32_t agg) {
                          pg->d_p);
       hipLaunchKernelGGL(nos::pgo_matvec_pose_kernel, dim3(pose_blocks), dim3(256), 0, slot.stream, pg->view, pg->d_hdiag,
                          lambda, pg->d_p, pg->d_p + N6, pg->d_ap, pg->d_partials, agg);
-      hipLaunchKernelGGL(nos::pgo_coarse_restrict_kernel, dim3(cblocks), dim3(128), 0, slot.stream, pg->view, agg, C, pg->d_ap,
-                         pg->c_b[0]);
+      hipLaunchKernelGGL(nos::pgo_coarse_restrict_kernel, dim3((C + 3) / 4), dim3(256), 0, slot.stream, pg->view, agg, C,
+                         pg->d_ap, pg->c_b[0]);
       hipLaunchKernelGGL(nos::pgo_coarse_scatter_kernel, dim3(cblocks), dim3(128), 0, slot.stream, C, colour, dof, pg->c_b[0],
                          pg->c_L[0], pg->c_D[0], pg->c_U[0]);
     }
@@ -154,7 +154,7 @@ int pgo_coarse_setup(nos_pose_graph* pg, double lambda, uint32_t agg) {
 int pgo_coarse_apply(nos_pose_graph* pg, const double* r, const double** xc) {
   DeviceSlot& slot = pg->ctx->slots[0];
   const uint32_t C = pg->n_agg, cblocks = (C + 127) / 128;
-  hipLaunchKernelGGL(nos::pgo_coarse_restrict_kernel, dim3(cblocks), dim3(128), 0, slot.stream, pg->view, pg->agg, C, r,
+  hipLaunchKernelGGL(nos::pgo_coarse_restrict_kernel, dim3((C + 3) / 4), dim3(256), 0, slot.stream, pg->view, pg->agg, C, r,
                      pg->c_b[0]);
   int cur = 0;
   for (uint32_t lvl = 0; lvl < pg->pcr_levels; ++lvl) {

@@ -156,14 +156,16 @@ __global__ __launch_bounds__(256) void pgo_coarse_probe_kernel(PgoView G, uint32
   for (int r = 0; r < 6; ++r) x[size_t(6) * i + r] = out[r];
 }
 
-// Restriction rc_J = Σ_{i in J} B_iᵀ y_i, one thread per aggregate, poses in index order.
-__global__ __launch_bounds__(128) void pgo_coarse_restrict_kernel(PgoView G, uint32_t agg, uint32_t n_agg,
+// Restriction rc_J = Σ_{i in J} B_iᵀ y_i: one WAVE per aggregate (lane l takes poses lo + l, lo + l + 64, …), the six sums
+// by the fixed butterfly of wave_sum — deterministic.  Launch with 256-thread blocks, ceil(n_agg / 4) of them.
+__global__ __launch_bounds__(256) void pgo_coarse_restrict_kernel(PgoView G, uint32_t agg, uint32_t n_agg,
                                                                   const double* __restrict__ y, double* __restrict__ rc) {
-  const uint32_t J = blockIdx.x * 128 + threadIdx.x;
-  if (J >= n_agg) return;
+  const uint32_t J = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t lane = threadIdx.x & 63u;
+  if (J >= n_agg) return;  // wave-uniform
   double acc[6] = {0, 0, 0, 0, 0, 0};
   const uint32_t lo = J * agg, hi = (lo + agg < G.n_poses) ? lo + agg : G.n_poses;
-  for (uint32_t i = lo; i < hi; ++i) {
+  for (uint32_t i = lo + lane; i < hi; i += 64u) {
     if (G.fixed[i]) continue;
     double B[36], yi[6];
     coarse_basis(G, i, agg, B);
@@ -178,7 +180,10 @@ __global__ __launch_bounds__(128) void pgo_coarse_restrict_kernel(PgoView G, uin
     }
   }
 #pragma unroll
-  for (int c = 0; c < 6; ++c) rc[size_t(6) * J + c] = acc[c];
+  for (int c = 0; c < 6; ++c) {
+    const double tot = wave_sum(acc[c]);
+    if (lane == 0) rc[size_t(6) * J + c] = tot;
+  }
 }
 
 // One probing product gives column `dof` of the blocks A_c(J, I) with I the aggregate of colour `colour` among J−1, J, J+1.
