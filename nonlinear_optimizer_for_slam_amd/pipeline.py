@@ -21,7 +21,8 @@ def _quat_vec_norm(R):
 
 def scan_to_map(ctx, ndt_map, scan, initial_pose=None, loss=("exponential", 1.0, 1.0), options=None,
                 max_outer_iterations=10, dof=6, dtype="f64", on_solve=None, indexed=False):
-    """ndt_map: api.NdtMap, scan: api.Scan.  → (Pose, list of per-round dicts).
+    """ndt_map: api.NdtMap, scan: api.Scan.  → (Pose, list of per-round dicts, outer_iter) — outer_iter as the
+    reference prints it (index of the round that met the stopping test, or max_outer_iterations).
 
     indexed=True: the matcher emits voxel ids instead of 120-byte records (nos_ndt_match_indexed) and the solver runs on
     the voxel-indexed layout — 2-3x less memory traffic per LM iteration for large scans (sort the scan by cell first:
