@@ -687,6 +687,26 @@ def main():
                 break
     except Exception:  # a missing / malformed summary only loses the optional field
         pass
+    # The other bound: vector-ALU issue.  VALU instructions per correspondence come from the committed SQ counter pass
+    # (SQ_INSTS_VALU) of the streaming kernel of this problem; one wave instruction occupies a SIMD for 4 cycles
+    # (MI355X_MICROARCH.md), 1024 SIMDs, 2.4 GHz.  Where this floor is close to the measured iteration the HBM fraction above
+    # is not the figure of merit (the resident reprojection solve: data on chip, no loads at all).
+    try:
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_*summary*.json")), reverse=True):
+            prof = json.load(open(path))
+            ipc = (prof.get("sq_derived") or {}).get("valu_instructions_per_correspondence")
+            if (ipc and prof.get("dtype") == args.dtype and prof.get("problem", "ndt6") == args.problem
+                    and "solve_cluster" not in prof.get("kernel", "")):
+                floor_ms = ipc * n_local / 64.0 * 4.0 / (1024.0 * 2.4e9) * 1e3
+                result["roofline"]["valu"] = {
+                    "instructions_per_corr": ipc, "floor_ms": floor_ms,
+                    "floor_over_ms_per_step": floor_ms / ms_med,
+                    "source": "NOT measured in this run: SQ_INSTS_VALU of %s; 4 cycles per wave instruction, 1024 SIMDs, 2.4 GHz"
+                              % os.path.relpath(path, ROOT)}
+                break
+    except Exception:
+        pass
     if host_loop is not None:
         result["host_loop"] = host_loop
     if cold_warm is not None:
