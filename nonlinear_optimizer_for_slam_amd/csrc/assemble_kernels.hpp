@@ -122,7 +122,58 @@ __device__ __forceinline__ T fast_rsqrt(T x) {
   }
 }
 
-// loss_function.h:28-33 / :57-66 ; LOSS == 0 is the `loss_function_ == nullptr` branch.
+// ---- value types of the item math.  The item functions below are written once for a value type V: the element type T
+// itself (one correspondence per call) or — fp32 only — a packed pair of floats (two correspondences per call: gfx950
+// has v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32; measured, the packed kernels are slower than the scalar ones, so the
+// pair form is a compile-time experiment only, see assemble_kernel).  Pose, loss parameters and masks stay scalar.
+using float2_t = float __attribute__((ext_vector_type(2)));
+
+template <typename V>
+struct Lanes {
+  static constexpr int n = 1;
+  using S = V;
+};
+template <>
+struct Lanes<float2_t> {
+  static constexpr int n = 2;
+  using S = float;
+};
+
+template <typename V>
+__device__ __forceinline__ V splat(typename Lanes<V>::S s) {
+  if constexpr (Lanes<V>::n == 2)
+    return V{s, s};
+  else
+    return s;
+}
+template <typename V>
+__device__ __forceinline__ V vfma(V a, V b, V c) {
+  if constexpr (Lanes<V>::n == 2)
+    return __builtin_elementwise_fma(a, b, c);
+  else
+    return fma(a, b, c);
+}
+// scalar coefficient (pose / intrinsics entry) times value plus value
+template <typename V>
+__device__ __forceinline__ V sfma(typename Lanes<V>::S a, V b, V c) {
+  return vfma<V>(splat<V>(a), b, c);
+}
+template <typename V>
+__device__ __forceinline__ typename Lanes<V>::S lane_get(const V& v, int k) {
+  if constexpr (Lanes<V>::n == 2)
+    return v[k];
+  else
+    return v;
+}
+template <typename V>
+__device__ __forceinline__ void lane_set(V& v, int k, typename Lanes<V>::S s) {
+  if constexpr (Lanes<V>::n == 2)
+    v[k] = s;
+  else
+    v = s;
+}
+
+// loss_function.h:28-33 / :57-66 ; LOSS == 0 is the `loss_function_ == nullptr` branch.  Scalar form:
 template <typename T, int LOSS>
 __device__ __forceinline__ void loss_eval(T s, T la, T lb, T lc, T& rho, T& w) {
   if constexpr (LOSS == kLossExponential) {
@@ -140,12 +191,25 @@ __device__ __forceinline__ void loss_eval(T s, T la, T lb, T lc, T& rho, T& w) {
     w = T(1);
   }
 }
+// value form: per lane through the scalar form (the transcendental / select part is not packable anyway)
+template <typename V, int LOSS>
+__device__ __forceinline__ void loss_eval_v(V s, typename Lanes<V>::S la, typename Lanes<V>::S lb, typename Lanes<V>::S lc,
+                                            V& rho, V& w) {
+  using S = typename Lanes<V>::S;
+#pragma unroll
+  for (int k = 0; k < Lanes<V>::n; ++k) {
+    S r1, w1;
+    loss_eval<S, LOSS>(lane_get<V>(s, k), la, lb, lc, r1, w1);
+    lane_set<V>(rho, k, r1);
+    lane_set<V>(w, k, w1);
+  }
+}
 
 // acc += w * JᵀJ (upper), w * Jᵀr for a ROWS×6 Jacobian held as J[row][6].
-template <typename T, int ROWS>
-__device__ __forceinline__ void rank_update6(const T (&J)[ROWS][6], const T (&r)[ROWS], T w,
-                                             T rho, T (&acc)[28]) {
-  T wJ[ROWS][6];
+template <typename V, int ROWS>
+__device__ __forceinline__ void rank_update6(const V (&J)[ROWS][6], const V (&r)[ROWS], V w,
+                                             V rho, V (&acc)[28]) {
+  V wJ[ROWS][6];
 #pragma unroll
   for (int a = 0; a < ROWS; ++a)
 #pragma unroll
@@ -155,30 +219,30 @@ __device__ __forceinline__ void rank_update6(const T (&J)[ROWS][6], const T (&r)
   for (int row = 0; row < 6; ++row)
 #pragma unroll
     for (int col = row; col < 6; ++col) {
-      T h = acc[k];
+      V h = acc[k];
 #pragma unroll
-      for (int a = 0; a < ROWS; ++a) h = fma(wJ[a][row], J[a][col], h);
+      for (int a = 0; a < ROWS; ++a) h = vfma<V>(wJ[a][row], J[a][col], h);
       acc[k] = h;
       ++k;
     }
 #pragma unroll
   for (int c = 0; c < 6; ++c) {
-    T gsum = acc[21 + c];
+    V gsum = acc[21 + c];
 #pragma unroll
-    for (int a = 0; a < ROWS; ++a) gsum = fma(wJ[a][c], r[a], gsum);
+    for (int a = 0; a < ROWS; ++a) gsum = vfma<V>(wJ[a][c], r[a], gsum);
     acc[21 + c] = gsum;
   }
   acc[27] += rho;
 }
 
 // M = -R [p]x, column form of ..._analytic_simd_various.cc:677-687.
-template <typename T>
-__device__ __forceinline__ void minus_R_hat(const T (&R)[9], T px, T py, T pz, T (&M)[3][3]) {
+template <typename V>
+__device__ __forceinline__ void minus_R_hat(const typename Lanes<V>::S (&R)[9], V px, V py, V pz, V (&M)[3][3]) {
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    M[i][0] = fma(R[3 * i + 2], py, -(R[3 * i + 1] * pz));
-    M[i][1] = fma(R[3 * i + 0], pz, -(R[3 * i + 2] * px));
-    M[i][2] = fma(R[3 * i + 1], px, -(R[3 * i + 0] * py));
+    M[i][0] = sfma<V>(R[3 * i + 2], py, -(splat<V>(R[3 * i + 1]) * pz));
+    M[i][1] = sfma<V>(R[3 * i + 0], pz, -(splat<V>(R[3 * i + 2]) * px));
+    M[i][2] = sfma<V>(R[3 * i + 1], px, -(splat<V>(R[3 * i + 0]) * py));
   }
 }
 
@@ -189,31 +253,36 @@ struct Ndt6Problem {
   static constexpr int kFields = 15;
   static constexpr int kOut = 28;
   using Params = Ndt6Params<T>;
-  // x = {p(3), mu(3), S row-major (9)}
-  __device__ static __forceinline__ void item(const T (&x)[15], const Params& P, bool /*valid*/,
-                                              T (&acc)[28]) {
-    T e[3], r[3], M[3][3], J[3][6];
+  // x = {p(3), mu(3), S row-major (9)}; V = T (one correspondence) or float2_t (two, fp32 only)
+  template <typename V = T>
+  __device__ static __forceinline__ void item(const V (&x)[15], const Params& P, const bool (&)[Lanes<V>::n] /*valid*/,
+                                              V (&acc)[28]) {
+    V e[3], r[3], M[3][3], J[3][6];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      const T pw = fma(P.R[3 * i], x[0], fma(P.R[3 * i + 1], x[1], fma(P.R[3 * i + 2], x[2], P.t[i])));
+      const V pw = sfma<V>(P.R[3 * i], x[0], sfma<V>(P.R[3 * i + 1], x[1], sfma<V>(P.R[3 * i + 2], x[2], splat<V>(P.t[i]))));
       e[i] = pw - x[3 + i];
     }
 #pragma unroll
     for (int a = 0; a < 3; ++a)
-      r[a] = fma(x[6 + 3 * a], e[0], fma(x[7 + 3 * a], e[1], x[8 + 3 * a] * e[2]));
-    minus_R_hat<T>(P.R, x[0], x[1], x[2], M);
+      r[a] = vfma<V>(x[6 + 3 * a], e[0], vfma<V>(x[7 + 3 * a], e[1], x[8 + 3 * a] * e[2]));
+    minus_R_hat<V>(P.R, x[0], x[1], x[2], M);
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
       for (int b = 0; b < 3; ++b) {
         J[a][b] = x[6 + 3 * a + b];
-        J[a][3 + b] = fma(x[6 + 3 * a], M[0][b], fma(x[7 + 3 * a], M[1][b], x[8 + 3 * a] * M[2][b]));
+        J[a][3 + b] = vfma<V>(x[6 + 3 * a], M[0][b], vfma<V>(x[7 + 3 * a], M[1][b], x[8 + 3 * a] * M[2][b]));
       }
-    const T s = fma(r[0], r[0], fma(r[1], r[1], r[2] * r[2]));
-    T rho, w;
-    loss_eval<T, LOSS>(s, P.la, P.lb, P.lc, rho, w);
+    const V s = vfma<V>(r[0], r[0], vfma<V>(r[1], r[1], r[2] * r[2]));
+    V rho, w;
+    loss_eval_v<V, LOSS>(s, P.la, P.lb, P.lc, rho, w);
     // zero-padded records have S = 0 → r = 0, J = 0, rho(0) = 0: no mask needed
-    rank_update6<T, 3>(J, r, w, rho, acc);
+    rank_update6<V, 3>(J, r, w, rho, acc);
+  }
+  __device__ static __forceinline__ void item(const T (&x)[15], const Params& P, bool valid, T (&acc)[28]) {
+    const bool v1[1] = {valid};
+    item<T>(x, P, v1, acc);
   }
 
   // Voxel-indexed form: the voxel table holds A = SᵀS (a00 a01 a02 a11 a12 a22) instead of S.  With J = [S | S M]:
@@ -280,26 +349,27 @@ struct Ndt3Problem {
   static constexpr int kFields = 15;
   static constexpr int kOut = 10;
   using Params = Ndt3Params<T>;
-  __device__ static __forceinline__ void item(const T (&x)[15], const Params& P, bool /*valid*/,
-                                              T (&acc)[10]) {
-    T e[3], r[3], J[3][3];
-    const T ux = x[0], uy = x[1];
-    e[0] = fma(P.R2[0], ux, fma(P.R2[1], uy, P.t2[0])) - x[3];
-    e[1] = fma(P.R2[2], ux, fma(P.R2[3], uy, P.t2[1])) - x[4];
+  template <typename V = T>
+  __device__ static __forceinline__ void item(const V (&x)[15], const Params& P, const bool (&)[Lanes<V>::n] /*valid*/,
+                                              V (&acc)[10]) {
+    V e[3], r[3], J[3][3];
+    const V ux = x[0], uy = x[1];
+    e[0] = sfma<V>(P.R2[0], ux, sfma<V>(P.R2[1], uy, splat<V>(P.t2[0]))) - x[3];
+    e[1] = sfma<V>(P.R2[2], ux, sfma<V>(P.R2[3], uy, splat<V>(P.t2[1]))) - x[4];
     e[2] = x[2] - x[5];
-    const T d0 = fma(P.R2[1], ux, -(P.R2[0] * uy));
-    const T d1 = fma(P.R2[3], ux, -(P.R2[2] * uy));
+    const V d0 = sfma<V>(P.R2[1], ux, -(splat<V>(P.R2[0]) * uy));
+    const V d1 = sfma<V>(P.R2[3], ux, -(splat<V>(P.R2[2]) * uy));
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      r[a] = fma(x[6 + 3 * a], e[0], fma(x[7 + 3 * a], e[1], x[8 + 3 * a] * e[2]));
+      r[a] = vfma<V>(x[6 + 3 * a], e[0], vfma<V>(x[7 + 3 * a], e[1], x[8 + 3 * a] * e[2]));
       J[a][0] = x[6 + 3 * a];
       J[a][1] = x[7 + 3 * a];
-      J[a][2] = fma(x[6 + 3 * a], d0, x[7 + 3 * a] * d1);
+      J[a][2] = vfma<V>(x[6 + 3 * a], d0, x[7 + 3 * a] * d1);
     }
-    const T s = fma(r[0], r[0], fma(r[1], r[1], r[2] * r[2]));
-    T rho, w;
-    loss_eval<T, LOSS>(s, P.la, P.lb, P.lc, rho, w);
-    T wJ[3][3];
+    const V s = vfma<V>(r[0], r[0], vfma<V>(r[1], r[1], r[2] * r[2]));
+    V rho, w;
+    loss_eval_v<V, LOSS>(s, P.la, P.lb, P.lc, rho, w);
+    V wJ[3][3];
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
@@ -309,13 +379,17 @@ struct Ndt3Problem {
     for (int row = 0; row < 3; ++row)
 #pragma unroll
       for (int col = row; col < 3; ++col) {
-        acc[k] = fma(wJ[0][row], J[0][col], fma(wJ[1][row], J[1][col], fma(wJ[2][row], J[2][col], acc[k])));
+        acc[k] = vfma<V>(wJ[0][row], J[0][col], vfma<V>(wJ[1][row], J[1][col], vfma<V>(wJ[2][row], J[2][col], acc[k])));
         ++k;
       }
 #pragma unroll
     for (int c = 0; c < 3; ++c)
-      acc[6 + c] = fma(wJ[0][c], r[0], fma(wJ[1][c], r[1], fma(wJ[2][c], r[2], acc[6 + c])));
+      acc[6 + c] = vfma<V>(wJ[0][c], r[0], vfma<V>(wJ[1][c], r[1], vfma<V>(wJ[2][c], r[2], acc[6 + c])));
     acc[9] += rho;
+  }
+  __device__ static __forceinline__ void item(const T (&x)[15], const Params& P, bool valid, T (&acc)[10]) {
+    const bool v1[1] = {valid};
+    item<T>(x, P, v1, acc);
   }
 
   // Voxel-indexed form with A = SᵀS: J = [S(:,0) S(:,1) S(:,0:2)·d] ⇒ JᵀJ = [[a00, a01, q0], [·, a11, q1], [·, ·, dᵀq]]
@@ -356,38 +430,59 @@ struct ReprojProblem {
   static constexpr int kFields = 5;
   static constexpr int kOut = 28;
   using Params = ReprojParams<T>;
-  // x = {X(3), pixel(2)}
-  __device__ static __forceinline__ void item(const T (&x)[5], const Params& P, bool valid,
-                                              T (&acc)[28]) {
-    T Xw[3], M[3][3], J[2][6], r[2];
+  // x = {X(3), pixel(2)}; V = T or float2_t
+  template <typename V = T>
+  __device__ static __forceinline__ void item(const V (&x)[5], const Params& P, const bool (&valid)[Lanes<V>::n],
+                                              V (&acc)[28]) {
+    using S = typename Lanes<V>::S;
+    V Xw[3], M[3][3], J[2][6], r[2];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
-      Xw[i] = fma(P.R[3 * i], x[0], fma(P.R[3 * i + 1], x[1], fma(P.R[3 * i + 2], x[2], P.t[i])));
+      Xw[i] = sfma<V>(P.R[3 * i], x[0], sfma<V>(P.R[3 * i + 1], x[1], sfma<V>(P.R[3 * i + 2], x[2], splat<V>(P.t[i]))));
     // depth test of ..._analytic.cc:119-123; pads (valid == false) contribute nothing
-    const bool ok = valid && !(Xw[2] < P.min_depth);
-    const T iz = fast_inv<T>(ok ? Xw[2] : T(1));
-    const T iz2 = iz * iz;
-    r[0] = fma(Xw[0], iz, -(P.inv_fx * (x[3] - P.cx)));
-    r[1] = fma(Xw[1], iz, -(P.inv_fy * (x[4] - P.cy)));
-    minus_R_hat<T>(P.R, x[0], x[1], x[2], M);
-    const T k02 = -Xw[0] * iz2, k12 = -Xw[1] * iz2;
+    bool ok[Lanes<V>::n];
+    V iz, mask;
+#pragma unroll
+    for (int k = 0; k < Lanes<V>::n; ++k) {
+      const S z = lane_get<V>(Xw[2], k);
+      ok[k] = valid[k] && !(z < P.min_depth);
+      lane_set<V>(iz, k, fast_inv<S>(ok[k] ? z : S(1)));
+      lane_set<V>(mask, k, ok[k] ? S(1) : S(0));
+    }
+    const V iz2 = iz * iz;
+    r[0] = vfma<V>(Xw[0], iz, -(splat<V>(P.inv_fx) * (x[3] - splat<V>(P.cx))));
+    r[1] = vfma<V>(Xw[1], iz, -(splat<V>(P.inv_fy) * (x[4] - splat<V>(P.cy))));
+    minus_R_hat<V>(P.R, x[0], x[1], x[2], M);
+    const V k02 = -Xw[0] * iz2, k12 = -Xw[1] * iz2;
     J[0][0] = iz;
-    J[0][1] = T(0);
+    J[0][1] = splat<V>(S(0));
     J[0][2] = k02;
-    J[1][0] = T(0);
+    J[1][0] = splat<V>(S(0));
     J[1][1] = iz;
     J[1][2] = k12;
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
-      J[0][3 + b] = fma(iz, M[0][b], k02 * M[2][b]);
-      J[1][3 + b] = fma(iz, M[1][b], k12 * M[2][b]);
+      J[0][3 + b] = vfma<V>(iz, M[0][b], k02 * M[2][b]);
+      J[1][3 + b] = vfma<V>(iz, M[1][b], k12 * M[2][b]);
     }
-    const T s = fma(r[0], r[0], r[1] * r[1]);
-    T rho, w;
-    loss_eval<T, LOSS>(ok ? s : T(0), P.la, P.lb, P.lc, rho, w);
-    w = ok ? w : T(0);
-    rho = ok ? rho : T(0);
-    rank_update6<T, 2>(J, r, w, rho, acc);
+    V s = vfma<V>(r[0], r[0], r[1] * r[1]);
+#pragma unroll
+    for (int k = 0; k < Lanes<V>::n; ++k)
+      if (!ok[k]) lane_set<V>(s, k, S(0));
+    V rho, w;
+    loss_eval_v<V, LOSS>(s, P.la, P.lb, P.lc, rho, w);
+#pragma unroll
+    for (int k = 0; k < Lanes<V>::n; ++k)
+      if (!ok[k]) {
+        lane_set<V>(w, k, S(0));
+        lane_set<V>(rho, k, S(0));
+      }
+    (void)mask;
+    rank_update6<V, 2>(J, r, w, rho, acc);
+  }
+  __device__ static __forceinline__ void item(const T (&x)[5], const Params& P, bool valid, T (&acc)[28]) {
+    const bool v1[1] = {valid};
+    item<T>(x, P, v1, acc);
   }
 };
 
@@ -882,6 +977,19 @@ __global__ __launch_bounds__(BLOCK, MINW) void assemble_kernel(TiledLayout L,
   T acc[kOut];
 #pragma unroll
   for (int k = 0; k < kOut; ++k) acc[k] = T(0);
+  // fp32 with an even number of correspondences per lane CAN run the item math on pairs (packed v_pk_* instructions) — and
+  // is SLOWER that way on gfx950: 0.0942 → 0.1068 ms per launch at 10 M (profiles/r02_tune_f32_packed.txt; the guide's
+  // constants table prices one v_pk_fma_f32 above two v_fma_f32).  Kept as a compile-time experiment (-DNOS_PACKED_F32).
+#ifdef NOS_PACKED_F32
+  constexpr bool kPacked = sizeof(T) == 4 && (ITEMS % 2 == 0) && !PREFETCH;
+#else
+  constexpr bool kPacked = false;
+#endif
+  [[maybe_unused]] float2_t acc2[kPacked ? kOut : 1];
+  if constexpr (kPacked) {
+#pragma unroll
+    for (int k = 0; k < kOut; ++k) acc2[k] = float2_t{0.0f, 0.0f};
+  }
 
   auto chunk_offset = [&](uint32_t c, uint64_t& i0) {
     i0 = uint64_t(c) * kChunk + uint64_t(threadIdx.x) * ITEMS;
@@ -931,14 +1039,29 @@ __global__ __launch_bounds__(BLOCK, MINW) void assemble_kernel(TiledLayout L,
       // with their uses in groups of 4-6 (seen in the ISA), which cuts the bytes a wave keeps in flight and costs ≈ 7 %
       // of the streaming rate.
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (kPacked) {
 #pragma unroll
-      for (int it = 0; it < ITEMS; ++it) {
-        T xi[kF];
+        for (int it = 0; it < ITEMS; it += 2) {
+          float2_t xi[kF];
 #pragma unroll
-        for (int f = 0; f < kF; ++f) xi[f] = x[f][it];
-        Problem::item(xi, P, (i0 + it) < L.n, acc);
+          for (int f = 0; f < kF; ++f) xi[f] = float2_t{x[f][it], x[f][it + 1]};
+          const bool valid2[2] = {(i0 + it) < L.n, (i0 + it + 1) < L.n};
+          Problem::template item<float2_t>(xi, P, valid2, acc2);
+        }
+      } else {
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+          T xi[kF];
+#pragma unroll
+          for (int f = 0; f < kF; ++f) xi[f] = x[f][it];
+          Problem::item(xi, P, (i0 + it) < L.n, acc);
+        }
       }
     }
+  }
+  if constexpr (kPacked) {
+#pragma unroll
+    for (int k = 0; k < kOut; ++k) acc[k] = acc2[k][0] + acc2[k][1];
   }
 
   double dacc[kOut];

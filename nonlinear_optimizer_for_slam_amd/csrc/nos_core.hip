@@ -181,7 +181,7 @@ int launch_by_variant(int variant, int blocks_per_cu, int num_cus, const nos::Ti
       // launch (0.0981 → 0.0968 ms fused, profiles/r02_tune_f32.txt) but lose it again in the back-to-back device loop
       // (0.1030 against 0.1011 ms per LM iteration), so the 16-byte-load form stays the default.
       NOS_CASE(0, 4, 256, 2, 1)
-      NOS_CASE(1, 2, 512, 4, 1)
+      NOS_CASE(1, 2, 512, 2, 1)  // the fp64 default's shape: 8-byte loads, two waves per SIMD
       NOS_CASE(2, 1, 256, 4, 2)
       NOS_CASE(3, 2, 256, 5, 2)
       NOS_CASE(4, 2, 256, 4, 2)
