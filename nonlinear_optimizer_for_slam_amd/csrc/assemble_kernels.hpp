@@ -587,6 +587,56 @@ __device__ __forceinline__ void block_reduce_store(const double (&acc)[NOUT], do
   }
 }
 
+// Same reduction, result returned instead of stored: thread k < NOUT of the block gets block total number k.
+template <int NOUT, int BLOCK>
+__device__ __forceinline__ double block_reduce_value(const double (&acc)[NOUT]) {
+  constexpr int kWaves = BLOCK / kWave;
+  __shared__ double lds_v[kWaves][NOUT];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x / kWave;
+  {
+    const double s = WaveScatter<NOUT>::run(acc);
+    constexpr int kShift = WaveScatter<NOUT>::kShift;
+    const int k = lane >> kShift;
+    if ((lane & ((1 << kShift) - 1)) == 0 && k < NOUT) lds_v[wave][k] = s;
+  }
+  __syncthreads();
+  double s = 0.0;
+  if (threadIdx.x < NOUT) {
+#pragma unroll
+    for (int wv = 0; wv < kWaves; ++wv) s += lds_v[wv][threadIdx.x];
+  }
+  return s;
+}
+
+// A value and the sequence number it belongs to in ONE naturally aligned 16-byte unit, written and read with single
+// 16-byte cache-bypassing accesses (global_store / global_load_dwordx4 sc1): the reader sees either the old pair or the
+// new pair, so "has it arrived" and "what is it" are one memory round trip, and the writer needs no drain between data
+// and flag (MI355X_MICROARCH.md lists 16-byte sc1 flag stores / polls among the measured-valid hand-off forms).
+struct alignas(16) TaggedUnit {
+  double value;
+  unsigned long long seq;
+};
+__device__ __forceinline__ void tagged_store(TaggedUnit* p, double value, unsigned long long seq) {
+  using V4 = unsigned int __attribute__((ext_vector_type(4)));
+  const unsigned long long bits = __double_as_longlong(value);
+  V4 w;
+  w[0] = (unsigned int)(bits & 0xFFFFFFFFull);
+  w[1] = (unsigned int)(bits >> 32);
+  w[2] = (unsigned int)(seq & 0xFFFFFFFFull);
+  w[3] = (unsigned int)(seq >> 32);
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(w) : "memory");
+}
+__device__ __forceinline__ TaggedUnit tagged_load(const TaggedUnit* p) {
+  using V4 = unsigned int __attribute__((ext_vector_type(4)));
+  V4 w;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(w) : "v"(p) : "memory");
+  TaggedUnit u;
+  u.value = __longlong_as_double(((unsigned long long)w[1] << 32) | w[0]);
+  u.seq = ((unsigned long long)w[3] << 32) | w[2];
+  return u;
+}
+
 // ---------------------------------------------------------------- in-launch final reduce
 
 // When `counter` is set the grid finishes its own reduction: every block publishes its row,
@@ -1271,7 +1321,7 @@ struct ResidentShape<5, 8> { static constexpr int RI = 9, LI = 7; };
 template <>
 struct ResidentShape<5, 4> { static constexpr int RI = 10, LI = 14; };
 
-template <typename Problem, typename T, int BLOCK, int RI, int LI>
+template <typename Problem, typename T, int BLOCK, int RI, int LI, int PROTO = 1>
 __global__ __launch_bounds__(BLOCK) void solve_cluster_kernel(TiledLayout L, typename Problem::Params P,
                                                              double* __restrict__ partials, LmDevice* lm, ClusterCtl* ctl,
                                                              double* __restrict__ cost_history, int history_capacity,
@@ -1332,6 +1382,8 @@ __global__ __launch_bounds__(BLOCK) void solve_cluster_kernel(TiledLayout L, typ
   if (threadIdx.x == 0) {
     s_state = lm->st;  // written by lm_init_kernel before this launch
     s_flag = s_state.done != 0 ? 1 : 0;
+    // a launch that finds `abort` raised (the test hook raises it beforehand) gives up at once, like one whose wait timed out
+    if (__hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) s_flag = 2;
 #pragma unroll
     for (int k = 0; k < 9; ++k) s_pose[k] = s_state.R[k];
 #pragma unroll
@@ -1386,8 +1438,80 @@ __global__ __launch_bounds__(BLOCK) void solve_cluster_kernel(TiledLayout L, typ
     double dacc[kOut];
 #pragma unroll
     for (int k = 0; k < kOut; ++k) dacc[k] = double(acc[k]);
-    double* rows = partials + size_t(it & 1u) * size_t(kClusterMaxBlocks) * kOut;  // this iteration's buffer
     NOS_RES_STAMP(0)  // item math
+    if constexpr (PROTO == 1) {
+      // ---- tagged two-stage all-reduce (round 2, second form): every sum travels as a 16-byte {value, iteration} unit.
+      //   stage 1: each workgroup publishes its 28 block sums; the LEADER of its group (workgroups 0..7 lead the groups
+      //            "index mod 8") spins on the units of its ≤ 32 members, adds them in member order, publishes 28 group sums;
+      //   stage 2: every workgroup spins on the 8 x 28 group units and adds them in group order.
+      // No counters, no drain between data and flag, two memory round trips on the critical path, ≈ 1 MB of polling
+      // traffic per iteration chip-wide instead of the 14.7 MB of "everybody reads every row".  Block rows need no double
+      // buffering (a workgroup publishes iteration k + 1 only after all group sums of k, i.e. after every leader has read
+      // the rows of k); group rows are double buffered by parity (a leader can run one iteration ahead of a reader in
+      // another group, not two).
+      TaggedUnit* const block_units = reinterpret_cast<TaggedUnit*>(partials);                       // [blocks][32]
+      TaggedUnit* const group_units = block_units + size_t(kClusterMaxBlocks) * 32;                 // [2][8][32]
+      // the tag is unique across launches too (the host's sequence number of this launch in the upper bits): no memset
+      const unsigned long long tag = (seq << 24) | ((unsigned long long)it + 1ull);
+      const double mine = block_reduce_value<kOut, BLOCK>(dacc);
+      if (threadIdx.x < kOut) tagged_store(block_units + size_t(blockIdx.x) * 32 + threadIdx.x, mine, tag);
+      NOS_RES_STAMP(1)  // block reduce + units issued
+      const unsigned long long deadline = wall_clock64() + kClusterTimeoutTicks;
+      // bounded spin on one unit; returns false when the launch is being abandoned
+      auto await = [&](const TaggedUnit* u, double* value) -> bool {
+        unsigned int polls = 0;
+        for (;;) {
+          const TaggedUnit got = tagged_load(u);
+          if (got.seq == tag) {
+            *value = got.value;
+            return true;
+          }
+          if ((++polls & 63u) == 0u &&
+              (__hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || wall_clock64() > deadline)) {
+            __hip_atomic_store(&ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_flag = 2;
+            return false;
+          }
+        }
+      };
+      const int col = threadIdx.x % kCols;    // which sum
+      const int slice = threadIdx.x / kCols;  // which member / group
+      if (blockIdx.x < n_groups) {            // block-uniform: this workgroup leads group blockIdx.x
+        const unsigned int g_size = (gridDim.x - blockIdx.x + 7u) >> 3;
+        double gsum = 0.0;
+        for (unsigned int m0 = 0; m0 < g_size; m0 += kSlices) {  // ≤ 2 passes of 16 members
+          const unsigned int m = m0 + slice;
+          double v = 0.0;
+          if (m < g_size && col < kOut)
+            (void)await(block_units + size_t(blockIdx.x + 8u * m) * 32 + col, &v);
+          red[slice][col] = v;
+          __syncthreads();
+          if (threadIdx.x < kOut) {
+#pragma unroll
+            for (int sl = 0; sl < kSlices; ++sl) gsum += red[sl][threadIdx.x];  // members in index order
+          }
+          __syncthreads();
+        }
+        if (threadIdx.x < kOut && s_flag != 2)
+          tagged_store(group_units + (size_t(it & 1u) * 8 + blockIdx.x) * 32 + threadIdx.x, gsum, tag);
+      }
+      {
+        double v = 0.0;
+        if (slice < int(n_groups) && col < kOut && s_flag != 2)
+          (void)await(group_units + (size_t(it & 1u) * 8 + slice) * 32 + col, &v);
+        if (slice < 8) red[slice][col] = v;
+      }
+      __syncthreads();
+      NOS_RES_STAMP(2)  // both stages arrived
+      if (s_flag == 2) break;  // block-uniform
+      if (threadIdx.x < kOut) {
+        double tot = 0.0;
+        for (unsigned int g = 0; g < n_groups; ++g) tot += red[g][threadIdx.x];  // groups in index order
+        s_tot[threadIdx.x] = tot;
+      }
+      __syncthreads();
+    } else {
+    double* rows = partials + size_t(it & 1u) * size_t(kClusterMaxBlocks) * kOut;  // this iteration's buffer
     block_reduce_store<kOut, BLOCK>(dacc, rows + size_t(blockIdx.x) * kOut, true);  // sc1 row
     NOS_RES_STAMP(1)  // block reduce + row store issued
     if (threadIdx.x < kWave) {
@@ -1451,6 +1575,9 @@ __global__ __launch_bounds__(BLOCK) void solve_cluster_kernel(TiledLayout L, typ
         s_tot[threadIdx.x] = tot;
       }
       __syncthreads();
+    }
+    }  // PROTO
+    {
       NOS_RES_STAMP(3)  // rows → sums
       if (threadIdx.x == 0) {
         double out[kOut];

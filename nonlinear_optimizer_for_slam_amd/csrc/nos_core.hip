@@ -210,6 +210,7 @@ struct SingleBlockArgs {
   // cluster form (one chunk per workgroup, whole loop in one launch) when cluster_blocks > 0
   int cluster_blocks = 0;
   int items_per_lane = 1;  // correspondences every lane keeps resident (registers + LDS, nos::ResidentShape)
+  int protocol = 1;        // hand-off form of the resident solve (Settings::lm_cluster == 3 selects 0)
   double* partials = nullptr;
   nos::ClusterCtl* ctl = nullptr;
   nos::LmDevice* lm;
@@ -229,15 +230,17 @@ int launch_single(const nos::TiledLayout& L, const typename Problem::Params& P, 
     if (a.items_per_lane < 1 || a.items_per_lane > Shape::RI + Shape::LI)
       return fail(NOS_ERR_INVALID_ARGUMENT, "resident solve: %d items per lane do not fit (%d + %d)", a.items_per_lane,
                   Shape::RI, Shape::LI);
-    const auto kernel = nos::solve_cluster_kernel<Problem, T, kBlock, Shape::RI, Shape::LI>;
+    // a.protocol: 1 = tagged two-stage all-reduce (default), 0 = arrival counters + every workgroup reads every row
+    const auto kernel = a.protocol == 0 ? nos::solve_cluster_kernel<Problem, T, kBlock, Shape::RI, Shape::LI, 0>
+                                        : nos::solve_cluster_kernel<Problem, T, kBlock, Shape::RI, Shape::LI, 1>;
     const size_t lds_items = a.items_per_lane > Shape::RI ? size_t(a.items_per_lane - Shape::RI) : 0;
     const size_t dyn_bytes = lds_items * size_t(Problem::kFields) * kBlock * sizeof(T);
-    static size_t lds_granted = 0;  // per instantiation: dynamic LDS beyond the default limit must be requested once
-    if (dyn_bytes > lds_granted) {
+    static size_t lds_granted[2] = {0, 0};  // per instantiation and protocol: dynamic LDS beyond the default limit is requested once
+    if (dyn_bytes > lds_granted[a.protocol == 0 ? 0 : 1]) {
       const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(dyn_bytes));
       if (ea != hipSuccess) return fail(NOS_ERR_HIP, "resident solve: %zu bytes of LDS refused: %s", dyn_bytes, hipGetErrorString(ea));
-      lds_granted = dyn_bytes;
+      lds_granted[a.protocol == 0 ? 0 : 1] = dyn_bytes;
     }
     hipLaunchKernelGGL(kernel, dim3(a.cluster_blocks), dim3(kBlock), dyn_bytes, stream, L, P, a.partials, a.lm, a.ctl,
                        a.history, a.history_capacity, a.entry, a.seq_host, a.seq, uint32_t(a.items_per_lane));
@@ -696,6 +699,7 @@ int lm_solve(nos_dataset* ds, const Request& rq, const nos_lm_options* opt, doub
     SingleBlockArgs cl{};
     cl.cluster_blocks = int(cluster_blocks);
     cl.items_per_lane = int(items_per_lane);
+    cl.protocol = ctx->settings.lm_cluster == 3 ? 0 : 1;
     cl.partials = slot.partials;
     cl.ctl = slot.d_cluster;
     cl.lm = slot.d_lm;
