@@ -435,7 +435,7 @@ struct ReprojProblem {
   __device__ static __forceinline__ void item(const V (&x)[5], const Params& P, const bool (&valid)[Lanes<V>::n],
                                               V (&acc)[28]) {
     using S = typename Lanes<V>::S;
-    V Xw[3], M[3][3], J[2][6], r[2];
+    V Xw[3], J[2][6], r[2];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
       Xw[i] = sfma<V>(P.R[3 * i], x[0], sfma<V>(P.R[3 * i + 1], x[1], sfma<V>(P.R[3 * i + 2], x[2], splat<V>(P.t[i]))));
@@ -450,9 +450,9 @@ struct ReprojProblem {
       lane_set<V>(mask, k, ok[k] ? S(1) : S(0));
     }
     const V iz2 = iz * iz;
+    // (pixel − c) first: the difference is (nearly) exact, so fp32 keeps its digits in the residual
     r[0] = vfma<V>(Xw[0], iz, -(splat<V>(P.inv_fx) * (x[3] - splat<V>(P.cx))));
     r[1] = vfma<V>(Xw[1], iz, -(splat<V>(P.inv_fy) * (x[4] - splat<V>(P.cy))));
-    minus_R_hat<V>(P.R, x[0], x[1], x[2], M);
     const V k02 = -Xw[0] * iz2, k12 = -Xw[1] * iz2;
     J[0][0] = iz;
     J[0][1] = splat<V>(S(0));
@@ -460,10 +460,17 @@ struct ReprojProblem {
     J[1][0] = splat<V>(S(0));
     J[1][1] = iz;
     J[1][2] = k12;
+    // rotation block: row_a · (−R [X]x) = (X × u_a)ᵀ with u_a = R₀ᵀ/z + k_a2 R₂ᵀ (rows of R) — 24 operations instead
+    // of the 30 that go through M = −R [X]x
 #pragma unroll
-    for (int b = 0; b < 3; ++b) {
-      J[0][3 + b] = vfma<V>(iz, M[0][b], k02 * M[2][b]);
-      J[1][3 + b] = vfma<V>(iz, M[1][b], k12 * M[2][b]);
+    for (int a = 0; a < 2; ++a) {
+      const V ka = a == 0 ? k02 : k12;
+      V u[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) u[j] = sfma<V>(P.R[3 * a + j], iz, splat<V>(P.R[6 + j]) * ka);
+      J[a][3] = vfma<V>(x[1], u[2], -(x[2] * u[1]));
+      J[a][4] = vfma<V>(x[2], u[0], -(x[0] * u[2]));
+      J[a][5] = vfma<V>(x[0], u[1], -(x[1] * u[0]));
     }
     V s = vfma<V>(r[0], r[0], r[1] * r[1]);
 #pragma unroll
@@ -570,6 +577,24 @@ __device__ __forceinline__ double wave_sum(double v) {
 // phase: at 28 values and 8 waves per CU the independent form kept the LDS crossbar busy for ≈ 6-12 µs at the end of
 // every launch.  On return lane L holds the wave total of value number  L >> (6 - log2 P)  (lanes that share a value
 // number hold the same total).  Fixed order of additions → bit-identical results run to run.
+// v_permlane32_swap (rows16 = false): lanes 32-63 of `a` trade places with lanes 0-31 of `b`;
+// v_permlane16_swap (rows16 = true): the odd 16-lane rows of `a` trade places with the even rows of `b`.
+__device__ __forceinline__ void swap_lane_halves(double& a, double& b, bool rows16) {
+  const unsigned long long ab = __double_as_longlong(a), bb = __double_as_longlong(b);
+  unsigned int a0 = (unsigned int)ab, a1 = (unsigned int)(ab >> 32), b0 = (unsigned int)bb, b1 = (unsigned int)(bb >> 32);
+  if (rows16) {
+    const auto r0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+    const auto r1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+    a0 = r0[0], b0 = r0[1], a1 = r1[0], b1 = r1[1];
+  } else {
+    const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+    a0 = r0[0], b0 = r0[1], a1 = r1[0], b1 = r1[1];
+  }
+  a = __longlong_as_double(((unsigned long long)a1 << 32) | a0);
+  b = __longlong_as_double(((unsigned long long)b1 << 32) | b0);
+}
+
 template <int NOUT>
 struct WaveScatter {
   static constexpr int kP = NOUT > 16 ? 32 : (NOUT > 8 ? 16 : 8);
@@ -587,6 +612,17 @@ struct WaveScatter {
       const bool upper = (lane & mask) != 0;
 #pragma unroll
       for (int j = 0; j < half; ++j) {
+#ifndef NOS_SCATTER_BPERMUTE
+        // gfx950 half exchanges: after the swap the two registers hold, in every lane, this lane's kept value and its
+        // partner's copy of the same value — 2 swaps + 1 add per exchange instead of 2 ds_bpermute + 4 selects + 1 add,
+        // same operands, same bits (the reduce was VALU-issue bound: ≈ 1.8 µs of every resident LM iteration)
+        if (mask >= 16) {
+          double a = v[j], b = v[j + half];
+          swap_lane_halves(a, b, mask == 16);
+          v[j] = a + b;
+          continue;
+        }
+#endif
         const double send = upper ? v[j] : v[j + half];
         const double keep = upper ? v[j + half] : v[j];
         v[j] = keep + __shfl_xor(send, mask, kWave);
@@ -1461,9 +1497,15 @@ __global__ __launch_bounds__(BLOCK) void solve_cluster_kernel(TiledLayout L, typ
     T acc[kOut];
 #pragma unroll
     for (int k = 0; k < kOut; ++k) acc[k] = T(0);
+    // (fp64 only: the fp32 kernels spill when their items are interleaved)
+    if (sizeof(T) == 8 && J >= uint32_t(RI)) {  // grid-uniform; one straight-line block, so the scheduler can interleave the items
 #pragma unroll
-    for (int j = 0; j < RI; ++j)
-      if (uint32_t(j) < J) Problem::item(x[j], P, valid[j], acc);  // grid-uniform branch
+      for (int j = 0; j < RI; ++j) Problem::item(x[j], P, valid[j], acc);
+    } else {
+#pragma unroll
+      for (int j = 0; j < RI; ++j)
+        if (uint32_t(j) < J) Problem::item(x[j], P, valid[j], acc);
+    }
     if constexpr (LI > 0) {
       for (uint32_t j = RI; j < J; ++j) {
         T xi[kF];
