@@ -71,7 +71,13 @@ RcclApi* Rccl() {
 }
 
 
-constexpr size_t kDefaultTileLog2 = 0;  // planar planes with a skew (measured best and robust across sizes); > 0 = tiled
+// Default layout by element type (-1 = this rule; NOS_TILE_LOG2 / the "tile_log2" option / nos_ctx_set_layout override it):
+//   fp64: planar planes with a skew (measured best and robust across sizes);
+//   fp32: tiles of 1024 correspondences — one kernel chunk (512 lanes x 2) is one contiguous 60 KB block of memory;
+//         measured at 10 M: planar 16-byte loads 6.37 TB/s, tiled 8-byte loads with the next chunk prefetched 6.94 TB/s
+//         (profiles/r02_tune_f32_layout.txt).
+constexpr int kDefaultTileLog2 = -1;
+constexpr int kDefaultTileLog2F32 = 10;
 
 size_t elem_size(int dtype) { return dtype == NOS_F32 ? sizeof(float) : sizeof(double); }
 
@@ -117,7 +123,7 @@ size_t layout_elems(const nos::TiledLayout& L, int n_fields) {
 
 // Number of compiled geometry variants per dtype (see the NOS_CASE tables below; index 0
 // is the default).
-constexpr int kNumVariants = 7;
+constexpr int kNumVariants = 11;
 
 template <typename Problem, typename T, int ITEMS, int BLOCK, int MINW, bool PREFETCH = false>
 int launch_variant(const nos::TiledLayout& L, const typename Problem::Params& P, int grid_cap, int num_cus_hint,
@@ -175,18 +181,23 @@ int launch_by_variant(int variant, int blocks_per_cu, int num_cus, const nos::Ti
       NOS_CASE_PF(6, 1, 256, 2, 2)
     }
   } else {
+    if (variant == 0 && L.tile_stride != 0) variant = 8;  // the default follows the layout (see kDefaultTileLog2F32)
     switch (variant) {
       // fp32 item math keeps a SIMD's VALU busy 52 % of a wave's lifetime at ONE wave per SIMD (PMC,
       // profiles/r02_bench_ndt6_f32_summary.json).  Four waves per SIMD (variant 5) overlap loads and math better inside one
       // launch (0.0981 → 0.0968 ms fused, profiles/r02_tune_f32.txt) but lose it again in the back-to-back device loop
       // (0.1030 against 0.1011 ms per LM iteration), so the 16-byte-load form stays the default.
-      NOS_CASE(0, 4, 256, 2, 1)
+      NOS_CASE(0, 4, 256, 2, 1)      // default on planar planes: 16-byte loads, one wave per SIMD
       NOS_CASE(1, 2, 512, 2, 1)  // the fp64 default's shape: 8-byte loads, two waves per SIMD
       NOS_CASE(2, 1, 256, 4, 2)
       NOS_CASE(3, 2, 256, 5, 2)
       NOS_CASE(4, 2, 256, 4, 2)
       NOS_CASE(5, 1, 1024, 4, 1)  // four waves per SIMD, 4-byte loads
       NOS_CASE(6, 2, 1024, 4, 1)  // four waves per SIMD, 8-byte loads
+      NOS_CASE_PF(7, 4, 256, 2, 1)   // the default's shape, next chunk's loads in flight during the item math
+      NOS_CASE_PF(8, 2, 512, 2, 1)   // default on the tiled layout
+      NOS_CASE(9, 2, 256, 3, 3)      // three waves per SIMD from three small workgroups per CU
+      NOS_CASE_PF(10, 2, 256, 3, 3)
     }
   }
 #undef NOS_CASE
@@ -916,6 +927,7 @@ int alloc_shards(nos_ctx* ctx, nos_dataset* ds) {
   const size_t n = ds->n;
   const size_t per = (n + n_shards - 1) / size_t(n_shards);  // contiguous equal ranges
   int tile_log2 = ctx->tile_log2 >= 0 ? ctx->tile_log2 : ctx->settings.tile_log2;
+  if (tile_log2 < 0) tile_log2 = ds->dtype == NOS_F32 ? kDefaultTileLog2F32 : 0;
   if (tile_log2 != 0 && (tile_log2 < 10 || tile_log2 > 24)) return fail(NOS_ERR_INVALID_ARGUMENT, "tile_log2 out of range");
   ds->tile = tile_log2 > 0 ? (size_t(1) << tile_log2) : 0;
   ds->shards.resize(n_shards);

@@ -136,7 +136,7 @@ struct Settings {
   int lm_single = 1;         // NOS_LM_SINGLE       whole solve in one workgroup for tiny problems
   int lm_cluster = 1;        // NOS_LM_CLUSTER      whole solve in one launch, data resident on chip
   int pool = 1;              // NOS_POOL            device-buffer pool
-  int tile_log2 = 0;         // NOS_TILE_LOG2       0 = planar
+  int tile_log2 = -1;        // NOS_TILE_LOG2       -1 = by element type (fp64 planar, fp32 1024-item tiles), 0 = planar
   int ingest = 0;            // NOS_INGEST          0 auto, 1 pack (host gather), 2 unpack (device)
   int ingest_threads = 0;    // NOS_INGEST_THREADS  0 = min(16, hw / 2)
   int indexed_bpc = 1;       // NOS_INDEXED_BPC

@@ -154,19 +154,34 @@ def test_async_result_in_torch_tensor_matches_sync(ctx):
     ds.close()
 
 
-def test_every_launch_geometry_gives_the_same_sums(oracle):
+def test_every_launch_geometry_and_layout_gives_the_same_sums(oracle):
+    """Every compiled launch geometry on every dataset layout (planar planes, 1024- and 4096-item tiles; the fp32 default
+    is the 1024-item tile, the fp64 default planar).  A geometry whose chunk does not divide the tile, or that is not
+    compiled for the element type, must be refused with an error — never run."""
     planes = synth.ndt_planes(123_457, 4000)
     loss = ("exponential", 1.0, 1.0)
     want = oracle.ndt6_accumulate(planes, R_TEST, T_TEST, loss)
     c = Context((0,))
-    for dtype, rtol in (("f64", RTOL_F64), ("f32", RTOL_F32)):
-        ds = NdtDataset.from_planes(c, planes, dtype)
-        for variant in range(7):
-            for bpc in (0, 1, 4):
-                c.set_launch(bpc, variant)
-                helpers.assert_normal_equations_close(ds.accumulate6(R_TEST, T_TEST, loss), want, 6, rtol)
-        ds.close()
+    ran = refused = 0
+    for tile in (-1, 0, 10, 12):
+        c.set_option("tile_log2", tile)
+        for dtype, rtol in (("f64", RTOL_F64), ("f32", RTOL_F32)):
+            ds = NdtDataset.from_planes(c, planes, dtype)
+            for variant in range(11):
+                for bpc in (0, 1, 4):
+                    c.set_launch(bpc, variant)
+                    try:
+                        got = ds.accumulate6(R_TEST, T_TEST, loss)
+                    except RuntimeError:
+                        # fp64 has 7 geometries; the 2048-item chunk of fp32 geometry 6 does not fit a 1024-item tile
+                        assert (dtype == "f64" and variant >= 7) or (dtype == "f32" and variant == 6 and tile in (-1, 10))
+                        refused += 1
+                        continue
+                    helpers.assert_normal_equations_close(got, want, 6, rtol)
+                    ran += 1
+            ds.close()
     c.close()
+    assert ran >= 4 * 3 * (7 + 10) and refused > 0
 
 
 # ---------------------------------------------------------------- Solve() through the C++ classes

@@ -1,0 +1,12 @@
+#!/bin/bash
+set -o pipefail
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
+O=gpurun_out
+timeout -k 10 600 python -m pytest tests -q -m gpu -x 2>&1 | tail -3
+P='import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d["ms_per_step"], d["ms_per_step_trains"], d["roofline"]["frac"], d.get("host_loop",{}).get("ms_per_step"))'
+B="--no-cpu-baseline --no-strong-baseline --no-cold"
+for c in "ndt6 f32" "ndt3 f32" "ndt6 f64" "ndt3 f64"; do set -- $c; echo "$c"; python bench.py --problem $1 --dtype $2 $B 2>/dev/null | python -c "$P"; done
+echo "reproj f32 stream"; python bench.py --problem reproj --dtype f32 --loop stream $B 2>/dev/null | python -c "$P"
+echo "reproj f32 stream planar"; NOS_TILE_LOG2=0 python bench.py --problem reproj --dtype f32 --loop stream $B 2>/dev/null | python -c "$P"
+echo "reproj f32 resident"; python bench.py --problem reproj --dtype f32 $B 2>/dev/null | python -c "$P"

@@ -27,7 +27,7 @@ for dtype in dtypes:
         gb = ds.stream_bytes / 1e9
         for nt in (0, 1):
             ctx.set_option("nt", nt)
-            for variant in range(7):
+            for variant in [int(v) for v in os.environ.get("TUNE_VARIANTS", "0,1,2,3,4,5,6,7,8").split(",")]:
                 for bpc in (0, 1, 2, 3, 4):
                     ctx.set_launch(bpc, variant)
                     try:
