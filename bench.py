@@ -92,6 +92,7 @@ class Workload:
         if not r["ok"] or r["iterations"] != k or r["launches"] not in (1, k):  # 1: one-launch form at small sizes
             raise RuntimeError("device LM loop failed: %r" % (r,))
         self.rep[:4] = [r["iterations"], r["printed_cost"], r["last_cost"], r["final_lambda"]]
+        self.launches_of_last_solve = int(r["launches"])
 
     def _host_check(self, ok, k, rep):
         if not ok or int(rep[0]) != k:
@@ -641,8 +642,12 @@ def main():
                             comm_mode, " (north_star: one RCCL all-reduce of the 28 doubles per iteration)"
                             if comm_mode == "rccl-native" else "")),
             "loop": "device" if device_loop else "host",
-            "step": ("LM iteration, device resident: assemble kernel + in-launch final reduce%s + LDLT / pose update / "
-                     "lambda schedule on the GPU, next launch already queued"
+            # 1 = the whole K-step train ran inside ONE launch (data resident on chip, or streamed from HBM every
+            # iteration when it does not fit); K = one launch per iteration
+            "launches_per_train": getattr(work, "launches_of_last_solve", None) if device_loop else None,
+            "step": ("LM iteration, device resident: pass over the data + grid-wide reduce%s + LDLT / pose update / "
+                     "lambda schedule on the GPU (one launch for the whole loop when launches_per_train = 1, else one per "
+                     "iteration with the next launch already queued)"
                      % ("" if world == 1 else (" + in-launch mailbox all-reduce" if comm_mode == "mailbox"
                                                else " + RCCL all-reduce(28 f64) + step kernel")))
                     if device_loop else

@@ -1469,7 +1469,14 @@ struct ResidentShape<5, 8> { static constexpr int RI = 9, LI = 7; };
 template <>
 struct ResidentShape<5, 4> { static constexpr int RI = 10, LI = 14; };
 
-template <typename Problem, typename T, int BLOCK, int RI, int LI, int PROTO = 1>
+// SI > 0 selects the STREAMING form of the same kernel (instantiated with RI = LI = 0): the data set does not fit the
+// register files and LDS of the chip, so every LM iteration streams it from HBM again, in chunks of BLOCK * SI
+// correspondences taken grid-stride exactly like assemble_kernel does — but the loop still lives in ONE launch: no kernel
+// boundary, no launch prologue and no ticket + last-block reduce per iteration (≈ 5 µs of every iteration at 10 M), the
+// tagged all-reduce instead, and the first chunk of iteration k + 1 is already in flight while iteration k is being
+// reduced and stepped (it does not depend on the pose).  `items_per_lane` then carries the number of chunks.  SPF: the
+// next chunk's loads are issued before the current chunk is evaluated (fp32), NT: non-temporal loads.
+template <typename Problem, typename T, int BLOCK, int RI, int LI, int PROTO = 1, int SI = 0, bool SPF = false, bool NT = false>
 __global__ __launch_bounds__(BLOCK) void solve_cluster_kernel(TiledLayout L, typename Problem::Params P,
                                                              double* __restrict__ partials, LmDevice* lm, ClusterCtl* ctl,
                                                              double* __restrict__ cost_history, int history_capacity,
@@ -1506,8 +1513,22 @@ __global__ __launch_bounds__(BLOCK) void solve_cluster_kernel(TiledLayout L, typ
     for (int f = 0; f < kF; ++f) dst[f] = ok ? xt[f][0] : T(0);
     return ok;
   };
-  T x[RI][kF];
-  bool valid[RI];
+  T x[RI > 0 ? RI : 1][kF];
+  bool valid[RI > 0 ? RI : 1];
+  static_assert(SI == 0 || (RI == 0 && LI == 0), "the streaming form keeps nothing resident");
+  // streaming form: the chunk being evaluated next (the first one of every iteration is fetched ahead of time)
+  [[maybe_unused]] T xs[kF][SI > 0 ? SI : 1];
+  [[maybe_unused]] uint64_t xs_i0 = 0;
+  [[maybe_unused]] auto fetch_chunk = [&](uint32_t c, T (&dst)[kF][SI > 0 ? SI : 1]) -> uint64_t {
+    const uint64_t i0 = uint64_t(c) * (uint64_t(BLOCK) * (SI > 0 ? SI : 1)) + uint64_t(threadIdx.x) * (SI > 0 ? SI : 1);
+    const uint64_t off = (i0 >> L.tile_shift) * L.tile_stride + (i0 & L.tile_mask);
+#pragma unroll
+    for (int f = 0; f < kF; ++f) load_items<T, (SI > 0 ? SI : 1), NT>(base + off + uint64_t(f) * L.field_stride, dst[f]);
+    return i0;
+  };
+  if constexpr (SI > 0) {
+    if (blockIdx.x < items_per_lane) xs_i0 = fetch_chunk(blockIdx.x, xs);
+  }
 #pragma unroll
   for (int j = 0; j < RI; ++j) {
     valid[j] = false;
@@ -1572,6 +1593,42 @@ __global__ __launch_bounds__(BLOCK) void solve_cluster_kernel(TiledLayout L, typ
     T acc[kOut];
 #pragma unroll
     for (int k = 0; k < kOut; ++k) acc[k] = T(0);
+    if constexpr (SI > 0) {
+      const uint32_t n_chunks = J;
+      auto evaluate = [&](const T (&xc)[kF][SI > 0 ? SI : 1], uint64_t i0) {
+#pragma unroll
+        for (int it = 0; it < (SI > 0 ? SI : 1); ++it) {
+          T xi[kF];
+#pragma unroll
+          for (int f = 0; f < kF; ++f) xi[f] = xc[f][it];
+          Problem::item(xi, P, (i0 + it) < L.n, acc);
+        }
+      };
+      uint32_t c = blockIdx.x;
+      if constexpr (SPF) {
+        for (; c < n_chunks; c += gridDim.x) {
+          T xb[kF][SI > 0 ? SI : 1];
+          uint64_t i1 = 0;
+          const uint32_t cn = c + gridDim.x;
+          if (cn < n_chunks) i1 = fetch_chunk(cn, xb);
+          evaluate(xs, xs_i0);
+#pragma unroll
+          for (int f = 0; f < kF; ++f)
+#pragma unroll
+            for (int it = 0; it < (SI > 0 ? SI : 1); ++it) xs[f][it] = xb[f][it];
+          xs_i0 = i1;
+        }
+      } else {
+        while (c < n_chunks) {
+          __builtin_amdgcn_sched_barrier(0);  // all loads of a chunk before any of its math (see assemble_kernel)
+          evaluate(xs, xs_i0);
+          c += gridDim.x;
+          if (c < n_chunks) xs_i0 = fetch_chunk(c, xs);
+        }
+      }
+      // the first chunk of the NEXT iteration: in flight during the all-reduce and the step below
+      if (blockIdx.x < n_chunks) xs_i0 = fetch_chunk(blockIdx.x, xs);
+    } else
     // (fp64 only: the fp32 kernels spill when their items are interleaved)
     if (sizeof(T) == 8 && J >= uint32_t(RI)) {  // grid-uniform; one straight-line block, so the scheduler can interleave the items
 #pragma unroll

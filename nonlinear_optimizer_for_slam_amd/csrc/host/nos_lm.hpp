@@ -96,8 +96,15 @@ NOS_HD inline Quat ExpQuat(const double w[3]) {
     q.z = 0.5 * w[2];
   } else {
     const double half = 0.5 * theta;
-    const double k = sin(half) / theta;
-    q.w = cos(half);
+    double sn, cs;
+#if defined(__HIP_DEVICE_COMPILE__)
+    sincos(half, &sn, &cs);  // one argument reduction for both
+#else
+    sn = sin(half);
+    cs = cos(half);
+#endif
+    const double k = sn / theta;
+    q.w = cs;
     q.x = k * w[0];
     q.y = k * w[1];
     q.z = k * w[2];
@@ -113,11 +120,11 @@ NOS_HD inline void RightMultiplyNormalize(Quat* q, const Quat& d) {
   r.x = a.w * d.x + a.x * d.w + a.y * d.z - a.z * d.y;
   r.y = a.w * d.y + a.y * d.w + a.z * d.x - a.x * d.z;
   r.z = a.w * d.z + a.z * d.w + a.x * d.y - a.y * d.x;
-  const double n = sqrt(r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w);
-  q->w = r.w / n;
-  q->x = r.x / n;
-  q->y = r.y / n;
-  q->z = r.z / n;
+  const double inv_n = 1.0 / sqrt(r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w);  // one division (see SolveLdlt)
+  q->w = r.w * inv_n;
+  q->x = r.x * inv_n;
+  q->y = r.y * inv_n;
+  q->z = r.z * inv_n;
 }
 
 // Solve (A) x = b for a symmetric positive definite A (N ≤ 6) by LDLᵀ.  After the
@@ -134,32 +141,30 @@ NOS_HD inline bool SolveLdlt(const double* A, const double* b, double* x) {
   xm = Am.ldlt().solve(bm);
   return xm.allFinite();
 #else
-  double L[N][N] = {};
-  double D[N];
+  // Right-looking LDLᵀ on the lower triangle with reciprocal pivots: the trailing updates of one column are independent
+  // of each other (the step runs in ONE GPU lane inside the device-resident loop, where a chain of dependent fp64
+  // operations — and above all of divisions, ≈ 45 ns each — is what it costs: 6 divisions here instead of 21).
+  double a[N][N];
+  for (int i = 0; i < N; ++i)
+    for (int k = 0; k <= i; ++k) a[i][k] = A[N * i + k];
+  double inv[N];
   for (int j = 0; j < N; ++j) {
-    double d = A[N * j + j];
-    for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k] * D[k];
+    const double d = a[j][j];
     if (!(d > 0.0) || !(d <= DBL_MAX)) return false;
-    D[j] = d;
-    L[j][j] = 1.0;
-    for (int i = j + 1; i < N; ++i) {
-      double v = A[N * i + j];
-      for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k] * D[k];
-      L[i][j] = v / d;
-    }
+    inv[j] = 1.0 / d;
+    double l[N];
+    for (int i = j + 1; i < N; ++i) l[i] = a[i][j] * inv[j];
+    for (int i = j + 1; i < N; ++i)
+      for (int k = j + 1; k <= i; ++k) a[i][k] -= l[i] * a[k][j];
+    for (int i = j + 1; i < N; ++i) a[i][j] = l[i];  // column j of L
   }
   double y[N];
-  for (int i = 0; i < N; ++i) {
-    double v = b[i];
-    for (int k = 0; k < i; ++k) v -= L[i][k] * y[k];
-    y[i] = v;
-  }
-  for (int i = 0; i < N; ++i) y[i] /= D[i];
-  for (int i = N - 1; i >= 0; --i) {
-    double v = y[i];
-    for (int k = i + 1; k < N; ++k) v -= L[k][i] * x[k];
-    x[i] = v;
-  }
+  for (int i = 0; i < N; ++i) y[i] = b[i];
+  for (int k = 0; k < N; ++k)
+    for (int i = k + 1; i < N; ++i) y[i] -= a[i][k] * y[k];
+  for (int i = 0; i < N; ++i) x[i] = y[i] * inv[i];
+  for (int k = N - 1; k > 0; --k)
+    for (int i = 0; i < k; ++i) x[i] -= a[k][i] * x[k];
   return true;
 #endif
 }
@@ -275,7 +280,13 @@ NOS_HD inline void LmAdvance3(const LmSettings& s, const double out[10], LmState
   }
   st->t[0] += step[0];
   st->t[1] += step[1];
-  const double c = cos(step[2]), sn = sin(step[2]);
+  double c, sn;
+#if defined(__HIP_DEVICE_COMPILE__)
+  sincos(step[2], &sn, &c);
+#else
+  c = cos(step[2]);
+  sn = sin(step[2]);
+#endif
   const double a = st->R[0], b = st->R[1], d = st->R[2], e = st->R[3];
   st->R[0] = a * c + b * sn;  // linear ← linear · Rot2(δθ)   (Isometry2d::rotate)
   st->R[1] = b * c - a * sn;

@@ -222,6 +222,8 @@ struct SingleBlockArgs {
   int cluster_blocks = 0;
   int items_per_lane = 1;  // correspondences every lane keeps resident (registers + LDS, nos::ResidentShape)
   int protocol = 1;        // hand-off form of the resident solve (Settings::lm_cluster == 3 selects 0)
+  int stream_chunks = 0;   // > 0: the streaming form (nothing resident; this many chunks of 512 x SI per iteration)
+  bool nt = false;         // streaming form: non-temporal loads
   double* partials = nullptr;
   nos::ClusterCtl* ctl = nullptr;
   nos::LmDevice* lm;
@@ -236,6 +238,22 @@ template <typename Problem, typename T>
 int launch_single(const nos::TiledLayout& L, const typename Problem::Params& P, const SingleBlockArgs& a, hipStream_t stream) {
   constexpr int kBlock = 512;
   if (L.n_padded % kBlock != 0) return fail(NOS_ERR_INVALID_ARGUMENT, "n_padded %% 512 != 0");
+  if (a.cluster_blocks > 0 && a.stream_chunks > 0) {
+    // the whole loop in one launch, the data streamed from HBM every iteration (solve_cluster_kernel, SI > 0)
+    constexpr int kSI = sizeof(T) == 8 ? 1 : 2;        // fp64: 8-byte loads of one item; fp32: 8-byte loads of two
+    constexpr bool kSPF = sizeof(T) == 4;              // fp32: next chunk prefetched (the geometry of launch variant 8)
+    constexpr size_t kChunk = size_t(kBlock) * kSI;
+    if (L.n_padded % kChunk != 0 || (L.tile_stride != 0 && ((size_t(L.tile_mask) + 1) % kChunk) != 0))
+      return fail(NOS_ERR_INVALID_ARGUMENT, "streaming solve: layout not a multiple of the %zu-item chunk", kChunk);
+    if (size_t(a.stream_chunks) * kChunk != L.n_padded) return fail(NOS_ERR_INVALID_ARGUMENT, "streaming solve: chunk count does not match the layout");
+    const auto kernel = a.nt ? nos::solve_cluster_kernel<Problem, T, kBlock, 0, 0, 1, kSI, kSPF, true>
+                             : nos::solve_cluster_kernel<Problem, T, kBlock, 0, 0, 1, kSI, kSPF, false>;
+    hipLaunchKernelGGL(kernel, dim3(a.cluster_blocks), dim3(kBlock), 0, stream, L, P, a.partials, a.lm, a.ctl, a.history,
+                       a.history_capacity, a.entry, a.seq_host, a.seq, uint32_t(a.stream_chunks));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(NOS_ERR_HIP, "streaming solve launch failed: %s", hipGetErrorString(e));
+    return NOS_OK;
+  }
   if (a.cluster_blocks > 0) {
     using Shape = nos::ResidentShape<Problem::kFields, int(sizeof(T))>;
     if (a.items_per_lane < 1 || a.items_per_lane > Shape::RI + Shape::LI)
@@ -704,12 +722,24 @@ int lm_solve(nos_dataset* ds, const Request& rq, const nos_lm_options* opt, doub
   const size_t cluster_blocks = std::min<size_t>(max_blocks, (sh.layout.n + 511) / 512);
   const size_t items_per_lane = cluster_blocks > 0 ? (sh.layout.n + cluster_blocks * 512 - 1) / (cluster_blocks * 512) : 0;
   const size_t resident_capacity = ctx->settings.lm_cluster == 2 ? 1 : resident_items_per_lane(ds->n_fields, ds->dtype);
+  // Beyond what the chip can keep resident the same one-launch loop STREAMS the data every iteration (lm_cluster 1 only;
+  // 4 = resident form only, as before).  The chunk count must fit the kernel's 32-bit counter.
+  const size_t stream_chunk = size_t(512) * (ds->dtype == NOS_F64 ? 1 : 2);
+  const bool resident_fits = items_per_lane >= 1 && items_per_lane <= resident_capacity;
+  const bool stream_form = !resident_fits && ctx->settings.lm_cluster == 1 && items_per_lane >= 1 &&
+                           sh.layout.n_padded % stream_chunk == 0 && sh.layout.n_padded / stream_chunk < (size_t(1) << 31) &&
+                           (sh.layout.tile_stride == 0 || (size_t(sh.layout.tile_mask) + 1) % stream_chunk == 0);
   if (ds->kind != kKindNdtIndexed && !with_comm && ctx->shm_dev == nullptr && opt->max_iterations > 0 &&
-      cluster_blocks >= 1 && items_per_lane >= 1 && items_per_lane <= resident_capacity &&
+      cluster_blocks >= 1 && (resident_fits || stream_form) &&
       ctx->settings.lm_cluster != 0 && (opt->cost_history == nullptr || opt->max_iterations <= kHistCapacity)) {
     SingleBlockArgs cl{};
     cl.cluster_blocks = int(cluster_blocks);
     cl.items_per_lane = int(items_per_lane);
+    if (stream_form) {
+      cl.items_per_lane = 0;
+      cl.stream_chunks = int(sh.layout.n_padded / stream_chunk);
+      cl.nt = use_nontemporal(ds, sh);
+    }
     cl.protocol = ctx->settings.lm_cluster == 3 ? 0 : 1;
     cl.partials = slot.partials;
     cl.ctl = slot.d_cluster;
@@ -758,7 +788,7 @@ int lm_solve(nos_dataset* ds, const Request& rq, const nos_lm_options* opt, doub
       st.ok = int(e[nos::kLogOk]);
       const int executed = int(e[nos::kLogExecuted]);
 #ifdef NOS_LM_TIMING
-      fprintf(stderr, "[resident-timing] %d blocks x %d items/lane, %d iterations; workgroup 0, us per iteration: item math %.2f, "
+      fprintf(stderr, "[resident-timing] %d blocks x %d items/lane (0 = streamed), %d iterations; workgroup 0, us per iteration: item math %.2f, "
               "block reduce %.2f, drain+arrive+wait %.2f, rows->sums %.2f, LM step+barrier %.2f\n", cl.cluster_blocks,
               cl.items_per_lane, executed, e[50] * 0.01, e[51] * 0.01, e[52] * 0.01, e[53] * 0.01, e[54] * 0.01);
 #endif

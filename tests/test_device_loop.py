@@ -462,11 +462,51 @@ def test_resident_solve_with_several_items_per_lane_equals_the_launch_per_iterat
     ds.close()
 
 
-def test_beyond_the_resident_capacity_the_solve_falls_back_to_one_launch_per_iteration(ctx):
-    ds = NdtDataset.from_planes(ctx, synth.ndt_planes(600_000, 9000), "f64")  # > 4 x 131072
-    r = ds.solve6(np.eye(3), np.zeros(3), EXP, max_iterations=12)
-    assert r[2]["launches"] == r[2]["iterations"] or r[2]["launches"] > 1
-    with ctx.options(lm_cluster=2):  # round 1's form: at most one correspondence per lane
+def test_beyond_the_resident_capacity_the_one_launch_solve_streams_and_agrees_with_the_launch_loop(ctx):
+    """What the chip cannot keep resident is streamed from HBM every iteration — still inside one launch — and gives the
+    launch-per-iteration loop's answer (lm_cluster=4: resident form only, so that loop runs); both orders of summation are
+    fixed, they differ from each other in the last bits only."""
+    planes = synth.ndt_planes(600_000, 9000)  # > 4 x 131072: beyond the fp64 capacity; fp32 gets 1_000_000 below
+    for dtype, n, atol in (("f64", 600_000, 1e-12), ("f32", 1_000_000, 2e-6)):
+        p = planes if n == 600_000 else synth.ndt_planes(n, 15000)
+        ds = NdtDataset.from_planes(ctx, p, dtype)
+        R1, t1, r1 = ds.solve6(np.eye(3), np.zeros(3), EXP, max_iterations=12)
+        assert r1["launches"] == 1 and r1["ok"]
+        with ctx.options(lm_cluster=4):
+            R2, t2, r2 = ds.solve6(np.eye(3), np.zeros(3), EXP, max_iterations=12)
+        assert r2["launches"] > 1 and r2["iterations"] == r1["iterations"]
+        np.testing.assert_allclose(R1, R2, rtol=0, atol=atol)
+        np.testing.assert_allclose(t1, t2, rtol=0, atol=atol)
+        np.testing.assert_allclose(r1["cost_history"], r2["cost_history"], rtol=max(atol, 1e-12) * 10)
+        # planar problem through the same form
+        c, s_ = np.cos(0.02), np.sin(0.02)
+        a = ds.solve3(np.array([[c, -s_], [s_, c]]), np.array([0.05, -0.02]), EXP, max_iterations=8)
+        with ctx.options(lm_cluster=4):
+            b = ds.solve3(np.array([[c, -s_], [s_, c]]), np.array([0.05, -0.02]), EXP, max_iterations=8)
+        assert a[2]["launches"] == 1 and b[2]["launches"] > 1
+        np.testing.assert_allclose(a[0], b[0], rtol=0, atol=atol)
+        np.testing.assert_allclose(a[1], b[1], rtol=0, atol=atol)
+        ds.close()
+    # reprojection beyond its resident capacity (2 097 152 fp64 correspondences)
+    rp = ReprojDataset.from_planes(ctx, synth.reproj_planes(2_400_000), "f64")
+    hub = ("huber", synth.REPROJ_HUBER_THRESHOLD)
+    a = rp.solve(np.eye(3), np.zeros(3), synth.REPROJ_INTR4, hub, max_iterations=6)
+    with ctx.options(lm_cluster=4):
+        b = rp.solve(np.eye(3), np.zeros(3), synth.REPROJ_INTR4, hub, max_iterations=6)
+    assert a[2]["launches"] == 1 and b[2]["launches"] > 1 and a[2]["iterations"] == b[2]["iterations"]
+    np.testing.assert_allclose(a[0], b[0], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(a[1], b[1], rtol=0, atol=1e-12)
+    rp.close()
+    # an abandoned streaming launch (test hook: it finds `abort` raised) is redone by the launch loop, same answer
+    ds = NdtDataset.from_planes(ctx, planes, "f64")
+    with ctx.options(lm_cluster=4):
+        want = ds.solve6(np.eye(3), np.zeros(3), EXP, max_iterations=6)
+    with ctx.options(debug_cluster_abort=1):
+        got = ds.solve6(np.eye(3), np.zeros(3), EXP, max_iterations=6)
+    assert got[2]["launches"] > 1
+    np.testing.assert_array_equal(got[0], want[0])
+    np.testing.assert_array_equal(got[1], want[1])
+    with ctx.options(lm_cluster=2):  # round 1's form: at most one correspondence per lane, nothing streamed
         ds2 = NdtDataset.from_planes(ctx, synth.ndt_planes(200_000, 4000), "f64")
         assert ds2.solve6(np.eye(3), np.zeros(3), EXP, max_iterations=12)[2]["launches"] > 1
         ds2.close()
