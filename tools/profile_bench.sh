@@ -1,5 +1,6 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence for bench.py on the GPU box (run via gpurun), one set per problem / dtype:
+#   (default mode = the one-launch LM loop; ":stream" = one launch per iteration, the kernel a single nos_*_accumulate call runs)
 #   1. kernel trace + stats of `bench.py --problem P --dtype D` (the command the driver runs, fewer steps)
 #   2. FETCH_SIZE and WRITE_SIZE in separate --pmc passes (the TCC slots do not fit both)
 #   3. one SQ pass: wave cycles, VALU-active / wait / issue-stall quad-cycles, VALU instruction count
@@ -9,7 +10,7 @@ set -o pipefail
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=gpurun_out
-CASES=${1:-"ndt6:f64 ndt6:f32 ndt3:f64 reproj:f64 reproj:f64:stream reproj:f32:stream"}
+CASES=${1:-"ndt6:f64 ndt6:f32 ndt3:f64 reproj:f64 ndt6:f64:stream ndt6:f32:stream reproj:f64:stream reproj:f32:stream"}
 COMMON="--no-cpu-baseline --no-strong-baseline --no-cold"
 SQ="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU"
 for c in $CASES; do

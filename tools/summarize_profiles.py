@@ -24,13 +24,34 @@ def newest(pattern):
     return max(hits, key=os.path.getmtime) if hits else None
 
 
-def counters(run, names):
+# iterations of every device-loop call of one bench.py run, in dispatch order: first the 50-step probe of the prewarm, then
+# the warm-up, then the timed trains (tools/profile_bench.sh: --prewarm-ms 0 in the counter runs, so no further prewarm rounds)
+COUNTER_RUN_CALLS = [50, 5, 20]
+STATS_RUN_STEPS, STATS_RUN_REPEATS = 60, 3
+
+
+def counters(run, names, hot_kernel=None, per_call_iterations=None):
+    """Per-launch counter values of the hot kernel.  For the one-launch loop (a call spans many LM iterations) the values
+    of call k are divided by per_call_iterations[k]: what one pass over the data costs."""
     f = newest(os.path.join(src, run, "*", "*_counter_collection.csv"))
     if f is None:
         return None
     out = {}
     rows = [r for r in csv.DictReader(open(f)) if "assemble_kernel" in r["Kernel_Name"] or "solve_cluster" in r["Kernel_Name"]
             or "solve_resident" in r["Kernel_Name"]]
+    if hot_kernel is not None:
+        rows = [r for r in rows if r["Kernel_Name"] == hot_kernel]
+    if per_call_iterations is not None:
+        ids = sorted({int(r["Dispatch_Id"]) for r in rows})
+        if len(ids) != len(per_call_iterations):
+            out["warning"] = "expected %d calls of the one-launch kernel, saw %d" % (len(per_call_iterations), len(ids))
+            per_call_iterations = None
+        else:
+            scale = {d: float(per_call_iterations[k]) for k, d in enumerate(ids)}
+            for r in rows:
+                if r["Counter_Name"] not in ("SQ_WAVES",):
+                    r["Counter_Value"] = float(r["Counter_Value"]) / scale[int(r["Dispatch_Id"])]
+            out["normalisation"] = "per LM iteration: every call's value divided by its iteration count %s" % per_call_iterations
     for name in names:
         vals = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == name]
         if vals:
@@ -56,10 +77,12 @@ for stats_json in sorted(glob.glob(os.path.join(src, "prof_*_stats.json"))):
     hot = [r for r in rows if "assemble_kernel" in r["Name"] or "solve_cluster" in r["Name"] or "solve_resident" in r["Name"]]
     hot.sort(key=lambda r: -float(r["TotalDurationNs"]))
     k = hot[0]
-    fetch = counters("prof_%s_fetch" % base, ["FETCH_SIZE"])
-    write = counters("prof_%s_write" % base, ["WRITE_SIZE"])
+    one_launch = "solve_cluster" in k["Name"]
+    calls = COUNTER_RUN_CALLS if one_launch else None
+    fetch = counters("prof_%s_fetch" % base, ["FETCH_SIZE"], k["Name"], calls)
+    write = counters("prof_%s_write" % base, ["WRITE_SIZE"], k["Name"], calls)
     sq = counters("prof_%s_sq" % base, ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY",
-                                        "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_INSTS_VALU"])
+                                        "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_INSTS_VALU"], k["Name"], calls)
     algo = bench["roofline"]["algorithmic_bytes_per_launch"]
     n = bench["config"]["points_per_gpu"]
     summary = {
@@ -75,13 +98,24 @@ for stats_json in sorted(glob.glob(os.path.join(src, "prof_*_stats.json"))):
         "achieved_GBps_from_rocprof_avg": algo / float(k["AverageNs"]),
         "frac_of_8000": algo / float(k["AverageNs"]) / 8000.0,
     }
-    if "solve_cluster" in k["Name"]:
-        # resident one-launch solve: one kernel call spans many LM iterations, its duration is not a per-iteration figure
-        for key in ("achieved_GBps_from_rocprof_avg", "frac_of_8000"):
-            summary.pop(key)
-        summary["note"] = ("the hot kernel is the resident solve (whole LM loop in one launch, data on chip): per-iteration time = "
-                           "bench_kernel_ms_same_run (bracket / iterations); the streaming kernel of this problem is profiled in "
-                           "the *stream* summary")
+    if one_launch:
+        # one-launch LM loop (data resident on chip, or streamed every iteration): one kernel call spans a whole train of LM
+        # iterations, so the per-iteration duration is  call duration / iterations of that call.  The timed trains are the
+        # STATS_RUN_REPEATS longest calls of the trace (STATS_RUN_STEPS iterations each).
+        trace = newest(os.path.join(src, "prof_%s_stats" % base, "*", "*_kernel_trace.csv"))
+        durs = sorted((int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(trace))
+                       if r["Kernel_Name"] == k["Name"]), reverse=True)[:STATS_RUN_REPEATS]
+        per_it = [d / float(STATS_RUN_STEPS) for d in durs]
+        avg = sum(per_it) / len(per_it)
+        summary.update({
+            "one_launch_loop": True, "iterations_per_timed_call": STATS_RUN_STEPS, "timed_call_durations_ns": durs,
+            "rocprof_ns_per_iteration": {"mean": avg, "min": min(per_it), "max": max(per_it)},
+            "achieved_GBps_from_rocprof_avg": algo / avg, "frac_of_8000": algo / avg / 8000.0,
+            "note": "the hot kernel runs the whole LM loop in one launch; rocprof_avg_ns is the mean over calls of different "
+                    "lengths (prewarm 50, warm-up 10, timed 60 iterations) — the per-iteration figure is "
+                    "rocprof_ns_per_iteration (timed calls / 60), which is what bench.py's bracket reports as kernel_ms; the "
+                    "launch-per-iteration kernel of the same problem is profiled in the *stream* summary",
+        })
     if fetch and write and "FETCH_SIZE" in fetch and "WRITE_SIZE" in write:
         # gfx950: FETCH_SIZE (KB) tallies the 128-B requests of a coalesced streaming read at 64 B (MI355X_MICROARCH.md §HBM):
         # x2; WRITE_SIZE is exact.  Datasets below 256 MiB are served by the Infinity Cache when warm; its hits are counted.
