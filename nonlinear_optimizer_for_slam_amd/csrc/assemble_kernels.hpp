@@ -758,6 +758,22 @@ __device__ __forceinline__ void tagged_store(TaggedUnit* p, double value, unsign
   w[3] = (unsigned int)(seq >> 32);
   asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(w) : "memory");
 }
+// The same unit with a PLAIN store: the line stays in the storing CU's XCD L2, where a reader on the SAME XCD finds it with its
+// sc1 load (L1-bypassing, L2-served) without the trip through the fabric; a reader on another XCD never sees it.
+__device__ __forceinline__ void tagged_store_plain(TaggedUnit* p, double value, unsigned long long seq) {
+  using V4 = unsigned int __attribute__((ext_vector_type(4)));
+  const unsigned long long bits = __double_as_longlong(value);
+  V4 w;
+  w[0] = (unsigned int)(bits & 0xFFFFFFFFull);
+  w[1] = (unsigned int)(bits >> 32);
+  w[2] = (unsigned int)(seq & 0xFFFFFFFFull);
+  w[3] = (unsigned int)(seq >> 32);
+  asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(w) : "memory");
+}
+// XCD (XCC) this wave runs on, 0…7
+__device__ __forceinline__ unsigned int xcc_id() {
+  return __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 0xFu;  // hwreg(HW_REG_XCC_ID, 0, 4)
+}
 __device__ __forceinline__ TaggedUnit tagged_load(const TaggedUnit* p) {
   using V4 = unsigned int __attribute__((ext_vector_type(4)));
   V4 w;
@@ -1490,6 +1506,7 @@ __global__ __launch_bounds__(BLOCK) void solve_cluster_kernel(TiledLayout L, typ
   extern __shared__ __align__(16) unsigned char resident_raw[];  // [items_per_lane - RI][kF][BLOCK] of T
   T* resident = reinterpret_cast<T*>(resident_raw);
   __shared__ int s_flag;  // 0 go on, 1 loop finished, 2 abort
+  __shared__ int s_fast;  // 1 once every group has been seen to sit on one XCD: stage-1 units then stay in that XCD's L2
   __shared__ double red[kSlices][kCols];
   __shared__ double s_tot[kOut];
   __shared__ double s_pose[12];
@@ -1499,7 +1516,10 @@ __global__ __launch_bounds__(BLOCK) void solve_cluster_kernel(TiledLayout L, typ
   // This workgroup's correspondences, read ONCE: slot j of lane l is item  block_base + j * BLOCK + l  (a wave reads
   // consecutive items of one field per load).  Slots beyond n are zero records (contribute exactly nothing) and are
   // flagged invalid for the problems that mask.
-  const uint32_t J = items_per_lane;  // grid-uniform, 1 … RI + LI
+  const uint32_t J = items_per_lane & 0x7fffffffu;  // grid-uniform, 1 … RI + LI (streaming form: the number of chunks)
+  [[maybe_unused]] const bool allow_fast = (items_per_lane >> 31) == 0u;  // bit 31: keep stage 1 of the all-reduce on sc1 stores
+  [[maybe_unused]] constexpr int kXccCol = 28;
+  [[maybe_unused]] const unsigned int my_xcc = xcc_id();
   const uint64_t block_base = uint64_t(blockIdx.x) * BLOCK * J;
   auto fetch = [&](uint32_t j, T (&dst)[kF]) -> bool {
     const uint64_t i = block_base + uint64_t(j) * BLOCK + threadIdx.x;
@@ -1527,7 +1547,7 @@ __global__ __launch_bounds__(BLOCK) void solve_cluster_kernel(TiledLayout L, typ
     return i0;
   };
   if constexpr (SI > 0) {
-    if (blockIdx.x < items_per_lane) xs_i0 = fetch_chunk(blockIdx.x, xs);
+    if (blockIdx.x < J) xs_i0 = fetch_chunk(blockIdx.x, xs);
   }
 #pragma unroll
   for (int j = 0; j < RI; ++j) {
@@ -1551,6 +1571,7 @@ __global__ __launch_bounds__(BLOCK) void solve_cluster_kernel(TiledLayout L, typ
   if (threadIdx.x == 0) {
     s_state = lm->st;  // written by lm_init_kernel before this launch
     s_flag = s_state.done != 0 ? 1 : 0;
+    s_fast = 0;
     // a launch that finds `abort` raised (the test hook raises it beforehand) gives up at once, like one whose wait timed out
     if (__hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) s_flag = 2;
 #pragma unroll
@@ -1665,7 +1686,20 @@ __global__ __launch_bounds__(BLOCK) void solve_cluster_kernel(TiledLayout L, typ
       // the tag is unique across launches too (the host's sequence number of this launch in the upper bits): no memset
       const unsigned long long tag = (seq << 24) | ((unsigned long long)it + 1ull);
       const double mine = block_reduce_value<kOut, BLOCK>(dacc);
-      if (threadIdx.x < kOut) tagged_store(block_units + size_t(blockIdx.x) * 32 + threadIdx.x, mine, tag);
+      // Stage 1 stays inside an XCD when the placement allows it.  HIP promises nothing about which XCD a workgroup lands on
+      // (observed: round-robin, so the members of group "index mod 8" share one), so iteration 0 goes the placement-independent
+      // way (sc1 stores) and carries every workgroup's XCC id in unit 28; each leader counts the members that are NOT on its
+      // own XCD, the counts travel with the group sums, and only if all eight are zero do the following iterations use plain
+      // stage-1 stores (line kept in the shared L2: 2.9 -> 2.3 µs for both stages).  Stage 2 is cross-XCD by nature: sc1.
+      const bool probe = it == 0u && allow_fast;  // block-uniform
+      if (threadIdx.x < kOut) {
+        if (s_fast != 0)
+          tagged_store_plain(block_units + size_t(blockIdx.x) * 32 + threadIdx.x, mine, tag);
+        else
+          tagged_store(block_units + size_t(blockIdx.x) * 32 + threadIdx.x, mine, tag);
+      } else if (probe && threadIdx.x == kXccCol) {
+        tagged_store(block_units + size_t(blockIdx.x) * 32 + kXccCol, double(my_xcc), tag);
+      }
       NOS_RES_STAMP(1)  // block reduce + units issued
       const unsigned long long deadline = wall_clock64() + kClusterTimeoutTicks;
       // bounded spin on one unit; returns false when the launch is being abandoned
@@ -1693,22 +1727,24 @@ __global__ __launch_bounds__(BLOCK) void solve_cluster_kernel(TiledLayout L, typ
         for (unsigned int m0 = 0; m0 < g_size; m0 += kSlices) {  // ≤ 2 passes of 16 members
           const unsigned int m = m0 + slice;
           double v = 0.0;
-          if (m < g_size && col < kOut)
+          if (m < g_size && (col < kOut || (probe && col == kXccCol))) {
             (void)await(block_units + size_t(blockIdx.x + 8u * m) * 32 + col, &v);
+            if (col == kXccCol) v = v == double(my_xcc) ? 0.0 : 1.0;  // a member on another XCD
+          }
           red[slice][col] = v;
           __syncthreads();
-          if (threadIdx.x < kOut) {
+          if (threadIdx.x < kOut || (probe && threadIdx.x == kXccCol)) {
 #pragma unroll
             for (int sl = 0; sl < kSlices; ++sl) gsum += red[sl][threadIdx.x];  // members in index order
           }
           __syncthreads();
         }
-        if (threadIdx.x < kOut && s_flag != 2)
+        if ((threadIdx.x < kOut || (probe && threadIdx.x == kXccCol)) && s_flag != 2)
           tagged_store(group_units + (size_t(it & 1u) * 8 + blockIdx.x) * 32 + threadIdx.x, gsum, tag);
       }
       {
         double v = 0.0;
-        if (slice < int(n_groups) && col < kOut && s_flag != 2)
+        if (slice < int(n_groups) && (col < kOut || (probe && col == kXccCol)) && s_flag != 2)
           (void)await(group_units + (size_t(it & 1u) * 8 + slice) * 32 + col, &v);
         if (slice < 8) red[slice][col] = v;
       }
@@ -1719,6 +1755,10 @@ __global__ __launch_bounds__(BLOCK) void solve_cluster_kernel(TiledLayout L, typ
         double tot = 0.0;
         for (unsigned int g = 0; g < n_groups; ++g) tot += red[g][threadIdx.x];  // groups in index order
         s_tot[threadIdx.x] = tot;
+      } else if (probe && threadIdx.x == kXccCol) {
+        double strangers = 0.0;
+        for (unsigned int g = 0; g < n_groups; ++g) strangers += red[g][kXccCol];
+        s_fast = strangers == 0.0 ? 1 : 0;  // the same verdict in every workgroup
       }
       __syncthreads();
     } else {

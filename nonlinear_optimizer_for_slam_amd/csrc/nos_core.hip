@@ -224,6 +224,7 @@ struct SingleBlockArgs {
   int protocol = 1;        // hand-off form of the resident solve (Settings::lm_cluster == 3 selects 0)
   int stream_chunks = 0;   // > 0: the streaming form (nothing resident; this many chunks of 512 x SI per iteration)
   bool nt = false;         // streaming form: non-temporal loads
+  bool stage1_sc1 = false; // keep stage 1 of the tagged all-reduce on sc1 stores even where a group sits on one XCD (lm_cluster 5)
   double* partials = nullptr;
   nos::ClusterCtl* ctl = nullptr;
   nos::LmDevice* lm;
@@ -249,7 +250,7 @@ int launch_single(const nos::TiledLayout& L, const typename Problem::Params& P, 
     const auto kernel = a.nt ? nos::solve_cluster_kernel<Problem, T, kBlock, 0, 0, 1, kSI, kSPF, true>
                              : nos::solve_cluster_kernel<Problem, T, kBlock, 0, 0, 1, kSI, kSPF, false>;
     hipLaunchKernelGGL(kernel, dim3(a.cluster_blocks), dim3(kBlock), 0, stream, L, P, a.partials, a.lm, a.ctl, a.history,
-                       a.history_capacity, a.entry, a.seq_host, a.seq, uint32_t(a.stream_chunks));
+                       a.history_capacity, a.entry, a.seq_host, a.seq, uint32_t(a.stream_chunks) | (a.stage1_sc1 ? 0x80000000u : 0u));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(NOS_ERR_HIP, "streaming solve launch failed: %s", hipGetErrorString(e));
     return NOS_OK;
@@ -272,7 +273,8 @@ int launch_single(const nos::TiledLayout& L, const typename Problem::Params& P, 
       lds_granted[a.protocol == 0 ? 0 : 1] = dyn_bytes;
     }
     hipLaunchKernelGGL(kernel, dim3(a.cluster_blocks), dim3(kBlock), dyn_bytes, stream, L, P, a.partials, a.lm, a.ctl,
-                       a.history, a.history_capacity, a.entry, a.seq_host, a.seq, uint32_t(a.items_per_lane));
+                       a.history, a.history_capacity, a.entry, a.seq_host, a.seq,
+                       uint32_t(a.items_per_lane) | (a.stage1_sc1 ? 0x80000000u : 0u));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(NOS_ERR_HIP, "cluster solve launch failed: %s", hipGetErrorString(e));
     return NOS_OK;
@@ -726,7 +728,7 @@ int lm_solve(nos_dataset* ds, const Request& rq, const nos_lm_options* opt, doub
   // 4 = resident form only, as before).  The chunk count must fit the kernel's 32-bit counter.
   const size_t stream_chunk = size_t(512) * (ds->dtype == NOS_F64 ? 1 : 2);
   const bool resident_fits = items_per_lane >= 1 && items_per_lane <= resident_capacity;
-  const bool stream_form = !resident_fits && ctx->settings.lm_cluster == 1 && items_per_lane >= 1 &&
+  const bool stream_form = !resident_fits && (ctx->settings.lm_cluster == 1 || ctx->settings.lm_cluster == 5) && items_per_lane >= 1 &&
                            sh.layout.n_padded % stream_chunk == 0 && sh.layout.n_padded / stream_chunk < (size_t(1) << 31) &&
                            (sh.layout.tile_stride == 0 || (size_t(sh.layout.tile_mask) + 1) % stream_chunk == 0);
   if (ds->kind != kKindNdtIndexed && !with_comm && ctx->shm_dev == nullptr && opt->max_iterations > 0 &&
@@ -741,6 +743,7 @@ int lm_solve(nos_dataset* ds, const Request& rq, const nos_lm_options* opt, doub
       cl.nt = use_nontemporal(ds, sh);
     }
     cl.protocol = ctx->settings.lm_cluster == 3 ? 0 : 1;
+    cl.stage1_sc1 = ctx->settings.lm_cluster == 5;
     cl.partials = slot.partials;
     cl.ctl = slot.d_cluster;
     cl.lm = slot.d_lm;

@@ -134,7 +134,7 @@ struct Settings {
   int lm_fused = 1;          // NOS_LM_FUSED        LM step in the finishing workgroup
   int lm_window = 3;         // NOS_LM_WINDOW       launches kept in flight by the device loop
   int lm_single = 1;         // NOS_LM_SINGLE       whole solve in one workgroup for tiny problems
-  int lm_cluster = 1;        // NOS_LM_CLUSTER      whole solve in one launch (resident on chip, or streamed per iteration beyond that); 4 = resident form only, 3 = counter protocol, 2 = one item per lane, 0 = off
+  int lm_cluster = 1;        // NOS_LM_CLUSTER      whole solve in one launch (resident on chip, or streamed per iteration beyond that); 5 = all-reduce stage 1 always through sc1 stores, 4 = resident form only, 3 = counter protocol, 2 = one item per lane, 0 = off
   int pool = 1;              // NOS_POOL            device-buffer pool
   int tile_log2 = -1;        // NOS_TILE_LOG2       -1 = by element type (fp64 planar, fp32 1024-item tiles), 0 = planar
   int ingest = 0;            // NOS_INGEST          0 auto, 1 pack (host gather), 2 unpack (device)

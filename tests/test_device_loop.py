@@ -453,6 +453,12 @@ def test_resident_solve_with_several_items_per_lane_equals_the_launch_per_iterat
     assert one[2]["launches"] == 1 and one[2]["ok"], one[2]
     again = solve()
     assert np.array_equal(one[0], again[0]) and np.array_equal(one[1], again[1])  # bit-repeatable
+    # the all-reduce's stage 1 through the XCD's L2 (default where every group is seen to sit on one XCD) and through sc1
+    # stores (lm_cluster = 5) add the same numbers in the same order
+    with ctx.options(lm_cluster=5):
+        slow = solve()
+    assert slow[2]["launches"] == 1 and np.array_equal(one[0], slow[0]) and np.array_equal(one[1], slow[1])
+    assert np.array_equal(one[2]["cost_history"], slow[2]["cost_history"])
     with ctx.options(lm_cluster=0):
         many = solve()
     assert many[2]["launches"] > 1 and many[2]["iterations"] == one[2]["iterations"]

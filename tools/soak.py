@@ -1,5 +1,5 @@
-"""Soak: bit-repeatability of the solve forms (resident one-launch solve with the tagged all-reduce, the counter form of it,
-one launch per iteration) and of accumulate over many launches — the hand-off protocols under test.
+"""Soak: bit-repeatability of the solve forms (one-launch solve — resident or streamed — with the tagged all-reduce, stage 1
+through the XCD's L2 or through sc1 stores; the counter form of it; one launch per iteration) and of accumulate over many launches — the hand-off protocols under test.
 
 usage: python tools/soak.py [seconds]"""
 import os, sys, time
@@ -18,7 +18,8 @@ first = {}
 counts = {}
 t_end = time.time() + budget
 R_test = np.array([[0.9987, -0.0499, -0.0199], [0.0501, 0.9987, 0.0095], [0.0194, -0.0105, 0.9998]])
-FORMS = (("default", {}), ("counters", {"lm_cluster": 3}), ("per-iteration", {"lm_cluster": 0, "lm_single": 0}))
+FORMS = (("default", {}), ("sc1-stage1", {"lm_cluster": 5}), ("counters", {"lm_cluster": 3}),
+         ("per-iteration", {"lm_cluster": 0, "lm_single": 0}))
 rounds = 0
 while time.time() < t_end:
     for (kind, n), ds in sets.items():
@@ -34,6 +35,10 @@ while time.time() < t_end:
                 print("MISMATCH solve", kind, n, form, rounds, flush=True)
                 sys.exit(1)
             counts[(kind, n, form)] = counts.get((kind, n, form), 0) + 1
+            # the two stage-1 transports of the tagged all-reduce add the same numbers in the same order
+            if form == "sc1-stage1" and key != first[(kind, n, "default")]:
+                print("MISMATCH between stage-1 transports", kind, n, rounds, flush=True)
+                sys.exit(1)
         if kind != "reproj":
             out = ds.accumulate6(R_test, [-0.1, 0.05, 0.2], EXP).tobytes()
             first.setdefault((kind, n, "acc"), out)
