@@ -388,7 +388,13 @@ int nos_pgo_matvec(nos_pose_graph* pg, double lambda, const double* x, double* y
  * NOS_INDEXED_BPC, NOS_MATCH_DENSE, NOS_PGO_HOST_SCALARS, NOS_PGO_PRECOND, NOS_PGO_AGG); afterwards only through these setters (keys =
  * the names in lower case without the prefix, e.g. "lm_cluster"; "ingest": 0 auto, 1 pack, 2 unpack;
  * "debug_cluster_abort": test hook, makes the next one-launch solve give up and fall back).  Nothing on the solve /
- * accumulate path reads the environment. */
+ * accumulate path reads the environment.
+ *   "lm_cluster"  1 (default) the device-resident loop runs in ONE launch wherever it can: correspondences resident on chip
+ *                 up to the register + LDS capacity, streamed from HBM every iteration beyond it; 4 = one launch only for
+ *                 resident data (one launch per iteration above), 5 = as 1 with the all-reduce's first stage always through
+ *                 sc1 stores, 3 = the arrival-counter all-reduce, 2 = at most one correspondence per lane, 0 = off.
+ *   "tile_log2"   layout of datasets created afterwards: -1 (default) by element type — fp64 planar planes, fp32 tiles of
+ *                 1024 correspondences; 0 planar; 10…24 tiles of 2^k. */
 int nos_ctx_set_option(nos_ctx* ctx, const char* key, int value);
 int nos_ctx_get_option(const nos_ctx* ctx, const char* key, int* value);
 

@@ -1711,6 +1711,7 @@ __global__ __launch_bounds__(BLOCK) void solve_cluster_kernel(TiledLayout L, typ
             *value = got.value;
             return true;
           }
+          // (no back-off between polls: s_sleep 4 / 16 measured slower at 100 k — 6.2 → 6.3 / 6.8 µs — and no help at 10 M)
           if ((++polls & 63u) == 0u &&
               (__hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || wall_clock64() > deadline)) {
             __hip_atomic_store(&ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
