@@ -175,6 +175,18 @@ int nos_dataset_dtype(const nos_dataset* ds);
  * (n × planes × sizeof(element)); the figure roofline numbers are quoted against. */
 size_t nos_dataset_stream_bytes(const nos_dataset* ds);
 
+/* Semantics of the reference's fp32 ("SIMD") solver classes for solves and accumulates on this dataset (0 = off, the
+ * default: the scalar classes' semantics at whatever element type the dataset has):
+ *   NDT (6- and 3-DoF): the LM loop keeps lambda and previous_cost in float
+ *     (MDM/mahalanobis_distance_minimizer_analytic_simd.cc:38-39,99-101; ..._3dof_simd.cc:73-74,201-207);
+ *   reprojection: a correspondence counts when its depth is > 0 (instead of >= min_depth), the mask multiplies the
+ *     WEIGHT only — the robust loss of a masked correspondence is still added to the cost
+ *     (REM/reprojection_error_minimizer_analytic_simd.cc:66,92,134).
+ * The classes' tail drop (only floor(N/8)*8 correspondences are used) and their float 1/fx are the caller's side: create
+ * the dataset from the first floor(N/8)*8 records (the drop-in classes do, HipOptions::simd_class).  The lane arithmetic of
+ * the un-vendored simd_helper library is NOT reproduced digit for digit (parity unpinned for it). */
+int nos_dataset_set_simd_class(nos_dataset* ds, int on);
+
 /* Copy a dataset back to host planes (n_fields arrays of nos_dataset_size doubles, plane order
  * as above).  Diagnostics / tests only. */
 int nos_dataset_download(nos_dataset* ds, double* const planes[]);

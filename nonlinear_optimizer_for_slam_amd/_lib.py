@@ -34,6 +34,7 @@ C_ABI_SYMBOLS = (
     "nos_map_stats_get", "nos_map_stats_destroy", "nos_pgo_create", "nos_pgo_destroy", "nos_pgo_num_unknowns",
     "nos_pgo_linearize", "nos_pgo_solve", "nos_pgo_retract", "nos_pgo_get_state", "nos_pgo_get_vector",
     "nos_pgo_matvec", "nos_dataset_destroy", "nos_dataset_size", "nos_dataset_dtype", "nos_dataset_stream_bytes",
+    "nos_dataset_set_simd_class",
     "nos_ndt6_accumulate", "nos_ndt3_accumulate", "nos_reproj_accumulate",
     "nos_ndt6_accumulate_async", "nos_ndt3_accumulate_async", "nos_reproj_accumulate_async",
     "nos_ndt6_solve", "nos_ndt3_solve", "nos_reproj_solve",
@@ -147,6 +148,8 @@ def _declare(lib):
     lib.nos_pgo_get_vector.argtypes = [vp, i, dp]
     lib.nos_pgo_matvec.argtypes = [vp, ctypes.c_double, dp, dp]
     lib.nos_dataset_destroy.argtypes = [vp]
+    lib.nos_dataset_set_simd_class.argtypes = [vp, ctypes.c_int]
+    lib.nos_dataset_set_simd_class.restype = ctypes.c_int
     lib.nos_dataset_size.argtypes = [vp]
     lib.nos_dataset_size.restype = sz
     lib.nos_dataset_dtype.argtypes = [vp]

@@ -282,6 +282,13 @@ class _Dataset:
     def stream_bytes(self):
         return int(self._lib.nos_dataset_stream_bytes(self._h))
 
+    def set_simd_class(self, on=True):
+        """Semantics of the reference's fp32 ("SIMD") solver classes for this dataset (nos_dataset_set_simd_class): NDT —
+        float lambda / previous_cost in the LM loop; reprojection — depth > 0 mask on the weight only.  The tail drop
+        (first floor(N/8)*8 correspondences) is the caller's: create the dataset from that prefix."""
+        check(self._lib.nos_dataset_set_simd_class(self._h, int(bool(on))), "nos_dataset_set_simd_class")
+        return self
+
     @property
     def dtype(self):
         return "f32" if self._lib.nos_dataset_dtype(self._h) == NOS_F32 else "f64"

@@ -65,6 +65,7 @@ struct ReprojParams {
   T inv_fx, inv_fy, cx, cy;
   T min_depth;
   T la, lb, lc;
+  int simd_mask;  // 1: the fp32 class's validity rule — depth > 0, the mask scales the weight only (the loss still counts)
 };
 
 // ---------------------------------------------------------------- math helpers
@@ -503,8 +504,11 @@ struct ReprojProblem {
 #pragma unroll
     for (int k = 0; k < Lanes<V>::n; ++k) {
       const S z = lane_get<V>(Xw[2], k);
-      ok[k] = valid[k] && !(z < P.min_depth);
-      lane_set<V>(iz, k, fast_inv<S>(ok[k] ? z : S(1)));
+      // scalar class: z < 0.03 contributes nothing at all (REM/..._analytic.cc:111,119-123); fp32 class (P.simd_mask):
+      // z > 0 keeps the weight, and the residual / loss are evaluated regardless (REM/..._analytic_simd.cc:66-92)
+      ok[k] = valid[k] && (P.simd_mask != 0 ? (z > S(0)) : !(z < P.min_depth));
+      // (a depth of exactly 0 would make the reference's weight 0 x NaN; it is given 1/z = 1 here so the sums stay finite)
+      lane_set<V>(iz, k, fast_inv<S>((ok[k] || (P.simd_mask != 0 && valid[k] && z != S(0))) ? z : S(1)));
       lane_set<V>(mask, k, ok[k] ? S(1) : S(0));
     }
     const V iz2 = iz * iz;
@@ -533,14 +537,14 @@ struct ReprojProblem {
     V s = vfma<V>(r[0], r[0], r[1] * r[1]);
 #pragma unroll
     for (int k = 0; k < Lanes<V>::n; ++k)
-      if (!ok[k]) lane_set<V>(s, k, S(0));
+      if (!ok[k] && !(P.simd_mask != 0 && valid[k])) lane_set<V>(s, k, S(0));
     V rho, w;
     loss_eval_v<V, LOSS>(s, P.la, P.lb, P.lc, rho, w);
 #pragma unroll
     for (int k = 0; k < Lanes<V>::n; ++k)
       if (!ok[k]) {
         lane_set<V>(w, k, S(0));
-        lane_set<V>(rho, k, S(0));
+        if (!(P.simd_mask != 0 && valid[k])) lane_set<V>(rho, k, S(0));
       }
     (void)mask;
     // acc += w JᵀJ (upper), w Jᵀr with the structure of this Jacobian spelled out — row 0 = [a 0 c d0 d1 d2],
@@ -2071,9 +2075,9 @@ __attribute__((unused)) static __global__ void lm_init_kernel(LmDevice* lm, LmIn
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   nos_host::LmState st;
   if (a.dof == 6)
-    nos_host::LmInit6(&st, a.R, a.t, a.settings.max_iterations);
+    nos_host::LmInit6(&st, a.R, a.t, a.settings.max_iterations, a.settings.float_schedule);
   else
-    nos_host::LmInit3(&st, a.R, a.t, a.settings.max_iterations);
+    nos_host::LmInit3(&st, a.R, a.t, a.settings.max_iterations, a.settings.float_schedule);
   lm->st = st;
   lm->settings = a.settings;
 }

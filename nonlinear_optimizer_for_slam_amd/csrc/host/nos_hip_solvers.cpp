@@ -56,6 +56,12 @@ nos_host::LmSettings SettingsFrom(const Options& options) {
   return s;
 }
 
+nos_host::LmSettings SettingsFrom(const Options& options, const HipOptions& hip, bool ndt) {
+  nos_host::LmSettings settings = SettingsFrom(options);
+  settings.float_schedule = (hip.simd_class && ndt) ? 1 : 0;  // host loop; the device loop reads it off the dataset
+  return settings;
+}
+
 void FillReport(const nos_host::LmReport& lm, int status, HipSolveReport* rep) {
   rep->iterations = lm.iterations;
   rep->printed_cost = lm.printed_cost;
@@ -193,11 +199,15 @@ bool MahalanobisDistanceMinimizerHip::Prepare(const std::vector<Correspondence>&
   }
   size_t offsets[NOS_NDT_PLANES];
   NdtFieldOffsets(offsets);
-  const int rc = nos_ndt_dataset_create_from_records(runtime_->ctx(), correspondences.size(), correspondences.data(),
-                                                     sizeof(Correspondence), offsets, hip_options_.dtype, &prepared_);
+  const size_t count = hip_options_.simd_class ? SimdClassCount(correspondences.size(), hip_options_.simd_class_threads)
+                                               : correspondences.size();
+  int rc = nos_ndt_dataset_create_from_records(runtime_->ctx(), count, correspondences.data(), sizeof(Correspondence),
+                                               offsets, hip_options_.dtype, &prepared_);
+  if (rc == NOS_OK && hip_options_.simd_class) rc = nos_dataset_set_simd_class(prepared_, 1);
   if (rc != NOS_OK) {
     ReportFailure("nos_ndt_dataset_create_from_records", rc);
     report_.status = rc;
+    if (prepared_ != nullptr) nos_dataset_destroy(prepared_);
     prepared_ = nullptr;
     return false;
   }
@@ -248,7 +258,7 @@ bool MahalanobisDistanceMinimizerHip::RunLoop(const Options& options, nos_datase
                      [&](const nos_lm_options* o, nos_lm_report* r) { return nos_ndt6_solve(dataset, R, t, &loss, o, r); },
                      &lm, &status))
     lm = nos_host::RunLm6(
-        SettingsFrom(options),
+        SettingsFrom(options, hip_options_, true),
         [&](const double* Rc, const double* tc, double* out28) {
           status = nos_ndt6_accumulate(dataset, Rc, tc, &loss, out28);
           return status == NOS_OK;
@@ -277,7 +287,7 @@ bool MahalanobisDistanceMinimizerHip3DOF::RunLoop(const Options& options, nos_da
                      [&](const nos_lm_options* o, nos_lm_report* r) { return nos_ndt3_solve(dataset, R2, t2, &loss, o, r); },
                      &lm, &status))
     lm = nos_host::RunLm3(
-        SettingsFrom(options),
+        SettingsFrom(options, hip_options_, true),
         [&](const double* Rc, const double* tc, double* out10) {
           status = nos_ndt3_accumulate(dataset, Rc, tc, &loss, out10);
           return status == NOS_OK;
@@ -344,15 +354,21 @@ bool ReprojectionErrorMinimizerHip::Solve(const Options& options, const std::vec
   size_t offsets[NOS_REPROJ_PLANES];
   ReprojFieldOffsets(offsets);
   nos_dataset* dataset = nullptr;
-  int status = nos_reproj_dataset_create_from_records(runtime_->ctx(), correspondences.size(), correspondences.data(),
-                                                      sizeof(Correspondence), offsets, hip_options_.dtype, &dataset);
+  const size_t count = hip_options_.simd_class ? SimdClassCount(correspondences.size(), 1) : correspondences.size();
+  int status = nos_reproj_dataset_create_from_records(runtime_->ctx(), count, correspondences.data(), sizeof(Correspondence),
+                                                      offsets, hip_options_.dtype, &dataset);
+  if (status == NOS_OK && hip_options_.simd_class) status = nos_dataset_set_simd_class(dataset, 1);
   if (status != NOS_OK) {
     ReportFailure("nos_reproj_dataset_create_from_records", status);
     report_.status = status;
+    if (dataset != nullptr) nos_dataset_destroy(dataset);
     return false;
   }
-  const double intr[4] = {camera_intrinsics.inv_fx, camera_intrinsics.inv_fy, camera_intrinsics.cx,
-                          camera_intrinsics.cy};
+  double intr[4] = {camera_intrinsics.inv_fx, camera_intrinsics.inv_fy, camera_intrinsics.cx, camera_intrinsics.cy};
+  if (hip_options_.simd_class) {  // REM/..._analytic_simd.cc:29-30: 1.0f / fx, not the struct's double inv_fx
+    intr[0] = double(1.0f / float(camera_intrinsics.fx));
+    intr[1] = double(1.0f / float(camera_intrinsics.fy));
+  }
   double t[3], R[9];
   ReadPose(*pose, t, R);
   nos_host::LmReport lm;

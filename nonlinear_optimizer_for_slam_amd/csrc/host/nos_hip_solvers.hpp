@@ -35,7 +35,21 @@ struct HipOptions {
   bool print_cost_line{true};      // the reference's "COST: <previous_cost>, iter: <n>" stderr line
   bool device_loop{true};          // run the whole LM loop device-resident (nos_*_solve); false = host loop around
                                    // nos_*_accumulate.  Multi-device contexts always use the host loop.
+  // Semantics of the reference's fp32 ("SIMD") classes instead of the scalar classes' (nos_dataset_set_simd_class in
+  // include/nos.h), to be combined with dtype = NOS_F32 for the classes' arithmetic (the reference's own "SIMD … Double"
+  // variants are this with NOS_F64, results/maha_amd64.txt:16-21): only the first T * floor(floor(N/8)/T) * 8
+  // correspondences are used (T = simd_class_threads = the thread count of the executor the reference class would be
+  // given, 1 = none: MDM/..._analytic_simd.cc:46-69), float lambda / previous_cost (NDT), depth > 0 mask on the weight
+  // only and a float 1/fx (reprojection).  The lane arithmetic of the un-vendored simd_helper is not reproduced bit for bit.
+  bool simd_class{false};
+  int simd_class_threads{1};
 };
+
+// Correspondences the reference's fp32 classes actually use out of n (see HipOptions::simd_class).
+inline size_t SimdClassCount(size_t n, int threads) {
+  const size_t t = threads > 1 ? size_t(threads) : 1;
+  return t * ((n / 8) / t) * 8;
+}
 
 // What the last Solve() did (additive; the reference exposes only the stderr line).
 struct HipSolveReport {

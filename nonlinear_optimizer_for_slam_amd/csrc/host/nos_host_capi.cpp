@@ -5,6 +5,7 @@
 // arithmetic of their own.
 #include <cstddef>
 #include <chrono>
+#include <algorithm>
 #include <memory>
 #include <vector>
 
@@ -29,8 +30,12 @@ std::shared_ptr<LossFunction> MakeLoss(int kind, double a, double b) {
 HipOptions MakeHipOptions(int dtype, const int* device_ids, int n_devices, int print_cost_line) {
   HipOptions h;
   h.dtype = dtype;
-  h.print_cost_line = (print_cost_line & 1) != 0;  // flag word: bit 0 = print the COST line, bit 1 = host loop
+  // flag word: bit 0 = print the COST line, bit 1 = host loop, bit 2 = the fp32 classes' semantics (HipOptions::simd_class),
+  // bits 8-15 = simd_class_threads (0 = 1)
+  h.print_cost_line = (print_cost_line & 1) != 0;
   h.device_loop = (print_cost_line & 2) == 0;
+  h.simd_class = (print_cost_line & 4) != 0;
+  h.simd_class_threads = std::max(1, (print_cost_line >> 8) & 0xff);
   if (device_ids != nullptr && n_devices > 0) h.device_ids.assign(device_ids, device_ids + n_devices);
   return h;
 }
@@ -389,6 +394,7 @@ extern "C" int nos_host_ndt_solve_dataset(int dof, nos_dataset* dataset, int los
     HipOptions hip;
     hip.print_cost_line = (print_cost_line & 1) != 0;
     hip.device_loop = (print_cost_line & 2) == 0;
+    hip.simd_class = (print_cost_line & 4) != 0;  // host loop only: the device loop reads the flag off the dataset
     std::unique_ptr<mdm::MahalanobisDistanceMinimizerHip> solver;
     if (dof == 3)
       solver = std::make_unique<mdm::MahalanobisDistanceMinimizerHip3DOF>(hip);

@@ -196,6 +196,10 @@ struct LmSettings {
   int max_iterations = 40;
   double gradient_tolerance = 1e-6;
   double parameter_tolerance = 1e-6;
+  // 1: λ and previous_cost live in `float`, as in the reference's fp32 NDT classes (MDM/…_analytic_simd.cc:38-39,
+  // …_3dof_simd.cc:73-74: `float lambda = 0.001f; float previous_cost = numeric_limits<float>::max()`); the cost itself
+  // stays double there too.  Selected by the "SIMD class" semantics of a dataset (nos_dataset_set_simd_class).
+  int float_schedule = 0;
 };
 
 struct LmReport {
@@ -223,16 +227,25 @@ struct LmState {
   int ok = 1;         // 0 if the damped solve failed
 };
 
-NOS_HD inline void LmInit6(LmState* st, const double R[9], const double t[3], int max_iterations) {
+NOS_HD inline void LmInitSchedule(LmState* st, int float_schedule) {
+  if (float_schedule) {
+    st->lambda = double(0.001f);
+    st->previous_cost = double(FLT_MAX);
+  }
+}
+
+NOS_HD inline void LmInit6(LmState* st, const double R[9], const double t[3], int max_iterations, int float_schedule = 0) {
   *st = LmState();
+  LmInitSchedule(st, float_schedule);
   st->q = QuatFromMatrix(R);
   QuatToMatrix(st->q, st->R);
   for (int k = 0; k < 3; ++k) st->t[k] = t[k];
   st->done = max_iterations <= 0 ? 1 : 0;
 }
 
-NOS_HD inline void LmInit3(LmState* st, const double R2[4], const double t2[2], int max_iterations) {
+NOS_HD inline void LmInit3(LmState* st, const double R2[4], const double t2[2], int max_iterations, int float_schedule = 0) {
   *st = LmState();
+  LmInitSchedule(st, float_schedule);
   for (int k = 0; k < 4; ++k) st->R[k] = R2[k];
   st->t[0] = t2[0];
   st->t[1] = t2[1];
@@ -242,6 +255,23 @@ NOS_HD inline void LmInit3(LmState* st, const double R2[4], const double t2[2], 
 NOS_HD inline double NextLambda(double lambda, double cost, double previous_cost) {
   const double l = lambda * (cost > previous_cost ? 2.0 : 0.6);
   return l < kMinLambda ? kMinLambda : (l > kMaxLambda ? kMaxLambda : l);
+}
+// The same with λ in float: `lambda *= (cost > previous_cost ? 2.0 : 0.6)` (product in double, stored to float), then
+// std::clamp against float bounds (MDM/…_analytic_simd.cc:30-31,99-100).  `lambda` / `previous_cost` hold float values.
+NOS_HD inline double NextLambdaFloat(double lambda, double cost, double previous_cost) {
+  const float l = float(double(float(lambda)) * (cost > previous_cost ? 2.0 : 0.6));
+  const float lo = 1e-6f, hi = 1e-2f;
+  return double(l < lo ? lo : (l > hi ? hi : l));
+}
+// λ schedule + cost bookkeeping at the end of an iteration that did not converge
+NOS_HD inline void LmSchedule(const LmSettings& s, LmState* st) {
+  if (s.float_schedule) {
+    st->lambda = NextLambdaFloat(st->lambda, st->cost, st->previous_cost);
+    st->previous_cost = double(float(st->cost));
+  } else {
+    st->lambda = NextLambda(st->lambda, st->cost, st->previous_cost);
+    st->previous_cost = st->cost;
+  }
 }
 
 // One pass of the loop body after ComputeCostAndDerivatives: damped solve, pose update, the two convergence
@@ -264,8 +294,7 @@ NOS_HD inline void LmAdvance6(const LmSettings& s, const double out[28], LmState
     st->done = 1;
     return;
   }
-  st->lambda = NextLambda(st->lambda, st->cost, st->previous_cost);
-  st->previous_cost = st->cost;
+  LmSchedule(s, st);
   if (++st->iteration >= s.max_iterations) st->done = 1;
 }
 
@@ -296,8 +325,7 @@ NOS_HD inline void LmAdvance3(const LmSettings& s, const double out[10], LmState
     st->done = 1;
     return;
   }
-  st->lambda = NextLambda(st->lambda, st->cost, st->previous_cost);
-  st->previous_cost = st->cost;
+  LmSchedule(s, st);
   if (++st->iteration >= s.max_iterations) st->done = 1;
 }
 
@@ -315,7 +343,7 @@ inline LmReport ReportOf(const LmState& st) {
 template <typename Accumulate>
 inline LmReport RunLm6(const LmSettings& s, Accumulate&& accumulate, double t[3], double R[9]) {
   LmState st;
-  LmInit6(&st, R, t, s.max_iterations);
+  LmInit6(&st, R, t, s.max_iterations, s.float_schedule);
   while (!st.done) {
     double out[28];
     if (!accumulate(st.R, st.t, out)) {
@@ -333,7 +361,7 @@ inline LmReport RunLm6(const LmSettings& s, Accumulate&& accumulate, double t[3]
 template <typename Accumulate>
 inline LmReport RunLm3(const LmSettings& s, Accumulate&& accumulate, double t2[2], double R2[4]) {
   LmState st;
-  LmInit3(&st, R2, t2, s.max_iterations);
+  LmInit3(&st, R2, t2, s.max_iterations, s.float_schedule);
   while (!st.done) {
     double out[10];
     if (!accumulate(st.R, st.t, out)) {

@@ -400,6 +400,7 @@ int launch_assemble_raw(const nos_dataset* ds, const Shard& sh, const Request& r
     P.cx = rq.intr[2];
     P.cy = rq.intr[3];
     P.min_depth = rq.min_depth;
+    P.simd_mask = ds->simd_class;
     fill_loss(&rq.loss, P.la, P.lb, P.lc);
     return launch_by_loss<nos::ReprojProblem, double>(rq.loss_kind, variant, bpc, slot.num_cus, sh.layout, P, nt,
                                                       partials, fin, stream, rows_out, single);
@@ -412,6 +413,7 @@ int launch_assemble_raw(const nos_dataset* ds, const Shard& sh, const Request& r
   P.cx = float(rq.intr[2]);
   P.cy = float(rq.intr[3]);
   P.min_depth = float(rq.min_depth);
+  P.simd_mask = ds->simd_class;
   fill_loss(&rq.loss, P.la, P.lb, P.lc);
   return launch_by_loss<nos::ReprojProblem, float>(rq.loss_kind, variant, bpc, slot.num_cus, sh.layout, P, nt,
                                                    partials, fin, stream, rows_out, single);
@@ -664,11 +666,12 @@ int lm_solve(nos_dataset* ds, const Request& rq, const nos_lm_options* opt, doub
   init.settings.gradient_tolerance = opt->gradient_tolerance;
   init.settings.parameter_tolerance = opt->parameter_tolerance;
   init.dof = rq.n_out == 28 ? 6 : 3;
+  init.settings.float_schedule = (ds->simd_class != 0 && ds->kind != kKindReproj) ? 1 : 0;
   nos_host::LmState st;  // host mirror: what the log says after the last finished iteration
   if (init.dof == 6)
-    nos_host::LmInit6(&st, init.R, init.t, opt->max_iterations);
+    nos_host::LmInit6(&st, init.R, init.t, opt->max_iterations, init.settings.float_schedule);
   else
-    nos_host::LmInit3(&st, init.R, init.t, opt->max_iterations);
+    nos_host::LmInit3(&st, init.R, init.t, opt->max_iterations, init.settings.float_schedule);
   hipLaunchKernelGGL(nos::lm_init_kernel, dim3(1), dim3(1), 0, slot.stream, slot.d_lm, init);
   NOS_HIP_CHECK(hipGetLastError());
 
@@ -816,9 +819,9 @@ int lm_solve(nos_dataset* ds, const Request& rq, const nos_lm_options* opt, doub
     hipLaunchKernelGGL(nos::lm_init_kernel, dim3(1), dim3(1), 0, slot.stream, slot.d_lm, init);
     NOS_HIP_CHECK(hipGetLastError());
     if (init.dof == 6)
-      nos_host::LmInit6(&st, init.R, init.t, opt->max_iterations);
+      nos_host::LmInit6(&st, init.R, init.t, opt->max_iterations, init.settings.float_schedule);
     else
-      nos_host::LmInit3(&st, init.R, init.t, opt->max_iterations);
+      nos_host::LmInit3(&st, init.R, init.t, opt->max_iterations, init.settings.float_schedule);
   }
   const unsigned long long base_seq2 = slot.seq;
   int launched = 0, completed = 0;
@@ -1642,6 +1645,12 @@ int nos_dataset_destroy(nos_dataset* ds) {
   return NOS_OK;
 }
 
+int nos_dataset_set_simd_class(nos_dataset* ds, int on) {
+  if (!ds) return fail(NOS_ERR_INVALID_ARGUMENT, "dataset is NULL");
+  nosd::CtxGuard guard_(ds->ctx);
+  ds->simd_class = on != 0 ? 1 : 0;
+  return NOS_OK;
+}
 size_t nos_dataset_size(const nos_dataset* ds) { return ds ? ds->n : 0; }
 int nos_dataset_dtype(const nos_dataset* ds) { return ds ? ds->dtype : -1; }
 size_t nos_dataset_stream_bytes(const nos_dataset* ds) {

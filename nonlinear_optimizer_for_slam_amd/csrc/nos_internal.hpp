@@ -203,6 +203,7 @@ struct nos_dataset {
   int n_fields = 0;
   size_t n = 0;
   size_t tile = 0;
+  int simd_class = 0;  // nos_dataset_set_simd_class: the semantics of the reference's fp32 (SIMD) solver classes
   std::vector<nosd::Shard> shards;
 };
 

@@ -51,10 +51,15 @@ def _planes_arg(planes, count):
 
 
 class _HipSolverBase:
-    def __init__(self, device_ids=(0,), dtype="f64", print_cost_line=False, device_loop=True):
+    def __init__(self, device_ids=(0,), dtype="f64", print_cost_line=False, device_loop=True, simd_class=False,
+                 simd_class_threads=1):
         """device_loop: run the whole LM loop device-resident (nos_*_solve, the default on single-device contexts);
-        False = the host loop around nos_*_accumulate."""
+        False = the host loop around nos_*_accumulate.  simd_class: the semantics of the reference's fp32 classes
+        (HipOptions::simd_class: fp32, tail drop to T*floor(floor(N/8)/T)*8 with T = simd_class_threads, float lambda /
+        previous_cost for NDT, depth > 0 weight mask and float 1/fx for reprojection)."""
         self._loss = None
+        self.simd_class = bool(simd_class)
+        self.simd_class_threads = max(1, int(simd_class_threads))
         self.device_loop = device_loop
         self.device_ids = tuple(device_ids)
         self.dtype = dtype
@@ -62,7 +67,8 @@ class _HipSolverBase:
         self.report = None
 
     def _flags(self):
-        return int(bool(self.print_cost_line)) | (0 if self.device_loop else 2)
+        return (int(bool(self.print_cost_line)) | (0 if self.device_loop else 2) | (4 if self.simd_class else 0)
+                | ((self.simd_class_threads & 0xff) << 8))
 
     def SetLossFunction(self, loss):
         """loss: None | ("exponential", c1, c2) | ("huber", threshold)."""

@@ -134,6 +134,34 @@ def reproj_accumulate(planes, R, t, intr, loss=None, min_depth=0.03):
     return _pack(H, g, rho.sum(), TRI6)
 
 
+def reproj_accumulate_simd_class(planes, R, t, intr, loss=None):
+    """The fp32 class's rules in fp64 (REM/reprojection_error_minimizer_analytic_simd.cc:55-138): residual and Jacobian
+    of EVERY correspondence from its real depth, mask = depth > 0 multiplying the weight only (:66,92), the loss of a
+    masked correspondence still added to the cost (:134).  (The tail drop to floor(N/8)*8 is the caller's.)"""
+    X = planes[0:3].T
+    px = planes[3:5].T
+    R = np.asarray(R, dtype=np.float64).reshape(3, 3)
+    inv_fx, inv_fy, cx, cy = intr
+    Xw = X @ R.T + np.asarray(t)
+    inside = Xw[:, 2] > 0.0
+    iz = 1.0 / Xw[:, 2]
+    r = np.stack([Xw[:, 0] * iz - inv_fx * (px[:, 0] - cx), Xw[:, 1] * iz - inv_fy * (px[:, 1] - cy)], axis=1)
+    n = X.shape[0]
+    dK = np.zeros((n, 2, 3))
+    dK[:, 0, 0] = iz
+    dK[:, 0, 2] = -Xw[:, 0] * iz * iz
+    dK[:, 1, 1] = iz
+    dK[:, 1, 2] = -Xw[:, 1] * iz * iz
+    M = -np.einsum("ij,njk->nik", R, hat(X))
+    J = np.concatenate([dK, np.einsum("nij,njk->nik", dK, M)], axis=2)
+    s = np.einsum("ni,ni->n", r, r)
+    rho, w = loss_eval(loss, s)
+    w = w * inside
+    H = np.einsum("n,nki,nkj->ij", w, J, J)
+    g = np.einsum("n,nki,nk->i", w, J, r)
+    return _pack(H, g, rho.sum(), TRI6)
+
+
 def reproj_cost(planes, R, t, intr, loss=None, min_depth=0.03):
     r, _ = reproj_terms(planes, R, t, intr, min_depth)
     rho, _ = loss_eval(loss, np.einsum("ni,ni->n", r, r))
