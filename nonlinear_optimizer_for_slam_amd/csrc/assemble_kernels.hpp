@@ -21,6 +21,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <limits>
 
 #include "host/nos_lm.hpp"
 #include <stdint.h>
@@ -65,8 +66,21 @@ struct ReprojParams {
   T inv_fx, inv_fy, cx, cy;
   T min_depth;
   T la, lb, lc;
-  int simd_mask;  // 1: the fp32 class's validity rule — depth > 0, the mask scales the weight only (the loss still counts)
+  // Validity rules on the depth z = (R X + t)_z, set by the launcher (set_reproj_rules):
+  //   scalar class (REM/..._analytic.cc:111,119-123): a correspondence with z < min_depth contributes nothing at all
+  //     → thr_w = min_depth, loss_everywhere = 0;
+  //   fp32 class (REM/..._analytic_simd.cc:66-92,134): the WEIGHT counts where z > 0, residual and loss are evaluated for
+  //     every correspondence → thr_w = smallest positive number, loss_everywhere = 1.  (z == 0 exactly then gives the same
+  //     inf / NaN as in the reference; the damped solve reports the non-finite pivot instead of returning a pose.)
+  // The second rule is a uniform flag combined with the lane mask by scalar instructions: no vector-ALU cost.
+  T thr_w;
+  int loss_everywhere;
 };
+template <typename T>
+inline void set_reproj_rules(ReprojParams<T>& P, bool simd_class) {
+  P.thr_w = simd_class ? std::numeric_limits<T>::min() : P.min_depth;
+  P.loss_everywhere = simd_class ? 1 : 0;
+}
 
 // ---------------------------------------------------------------- math helpers
 
@@ -499,17 +513,14 @@ struct ReprojProblem {
     for (int i = 0; i < 3; ++i)
       Xw[i] = sfma<V>(P.R[3 * i], x[0], sfma<V>(P.R[3 * i + 1], x[1], sfma<V>(P.R[3 * i + 2], x[2], splat<V>(P.t[i]))));
     // depth test of ..._analytic.cc:119-123; pads (valid == false) contribute nothing
-    bool ok[Lanes<V>::n];
-    V iz, mask;
+    bool ok[Lanes<V>::n], okr[Lanes<V>::n];
+    V iz;
 #pragma unroll
     for (int k = 0; k < Lanes<V>::n; ++k) {
       const S z = lane_get<V>(Xw[2], k);
-      // scalar class: z < 0.03 contributes nothing at all (REM/..._analytic.cc:111,119-123); fp32 class (P.simd_mask):
-      // z > 0 keeps the weight, and the residual / loss are evaluated regardless (REM/..._analytic_simd.cc:66-92)
-      ok[k] = valid[k] && (P.simd_mask != 0 ? (z > S(0)) : !(z < P.min_depth));
-      // (a depth of exactly 0 would make the reference's weight 0 x NaN; it is given 1/z = 1 here so the sums stay finite)
-      lane_set<V>(iz, k, fast_inv<S>((ok[k] || (P.simd_mask != 0 && valid[k] && z != S(0))) ? z : S(1)));
-      lane_set<V>(mask, k, ok[k] ? S(1) : S(0));
+      ok[k] = valid[k] && !(z < P.thr_w);                          // the weight counts
+      okr[k] = ok[k] || (valid[k] && P.loss_everywhere != 0);      // residual and loss are evaluated
+      lane_set<V>(iz, k, fast_inv<S>(okr[k] ? z : S(1)));
     }
     const V iz2 = iz * iz;
     // (pixel − c) first: the difference is (nearly) exact, so fp32 keeps its digits in the residual
@@ -537,16 +548,15 @@ struct ReprojProblem {
     V s = vfma<V>(r[0], r[0], r[1] * r[1]);
 #pragma unroll
     for (int k = 0; k < Lanes<V>::n; ++k)
-      if (!ok[k] && !(P.simd_mask != 0 && valid[k])) lane_set<V>(s, k, S(0));
+      if (!okr[k]) lane_set<V>(s, k, S(0));
     V rho, w;
     loss_eval_v<V, LOSS>(s, P.la, P.lb, P.lc, rho, w);
 #pragma unroll
     for (int k = 0; k < Lanes<V>::n; ++k)
-      if (!ok[k]) {
-        lane_set<V>(w, k, S(0));
-        if (!(P.simd_mask != 0 && valid[k])) lane_set<V>(rho, k, S(0));
-      }
-    (void)mask;
+    {
+      if (!ok[k]) lane_set<V>(w, k, S(0));
+      if (!okr[k]) lane_set<V>(rho, k, S(0));
+    }
     // acc += w JᵀJ (upper), w Jᵀr with the structure of this Jacobian spelled out — row 0 = [a 0 c d0 d1 d2],
     // row 1 = [0 a e f0 f1 f2] (a = 1/z): 49 operations instead of the 66 of the generic 2x6 update (the kernel is
     // fp64-VALU bound when the data is resident)

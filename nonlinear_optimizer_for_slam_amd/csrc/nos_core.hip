@@ -400,7 +400,7 @@ int launch_assemble_raw(const nos_dataset* ds, const Shard& sh, const Request& r
     P.cx = rq.intr[2];
     P.cy = rq.intr[3];
     P.min_depth = rq.min_depth;
-    P.simd_mask = ds->simd_class;
+    nos::set_reproj_rules(P, ds->simd_class != 0);
     fill_loss(&rq.loss, P.la, P.lb, P.lc);
     return launch_by_loss<nos::ReprojProblem, double>(rq.loss_kind, variant, bpc, slot.num_cus, sh.layout, P, nt,
                                                       partials, fin, stream, rows_out, single);
@@ -413,7 +413,7 @@ int launch_assemble_raw(const nos_dataset* ds, const Shard& sh, const Request& r
   P.cx = float(rq.intr[2]);
   P.cy = float(rq.intr[3]);
   P.min_depth = float(rq.min_depth);
-  P.simd_mask = ds->simd_class;
+  nos::set_reproj_rules(P, ds->simd_class != 0);
   fill_loss(&rq.loss, P.la, P.lb, P.lc);
   return launch_by_loss<nos::ReprojProblem, float>(rq.loss_kind, variant, bpc, slot.num_cus, sh.layout, P, nt,
                                                    partials, fin, stream, rows_out, single);
