@@ -340,13 +340,13 @@ def test_cluster_solve_is_bit_repeatable_over_many_launches(ctx):
     b.close()
 
 
-def _cluster_contention_worker(rank, out_dir):
+def _cluster_contention_worker(rank, out_dir, n=120_000, voxels=3000, solves=60):
     import numpy as np
     from nonlinear_optimizer_for_slam_amd import Context, NdtDataset, synth
     ctx = Context((0,))
-    ds = NdtDataset.from_planes(ctx, synth.ndt_planes(120_000, 3000), "f64")   # 235 workgroups: nearly every CU
+    ds = NdtDataset.from_planes(ctx, synth.ndt_planes(n, voxels), "f64")   # 120 000: 235 workgroups, nearly every CU
     res = []
-    for _ in range(60):
+    for _ in range(solves):
         R, t, r = ds.solve6(np.eye(3), np.zeros(3), ("exponential", 1.0, 1.0), max_iterations=40)
         res.append((R.copy(), t.copy(), r["iterations"], r["launches"], r["ok"]))
     np.savez(os.path.join(out_dir, "cluster_rank%d.npz" % rank), R=np.array([x[0] for x in res]), t=np.array([x[1] for x in res]),
@@ -355,14 +355,16 @@ def _cluster_contention_worker(rank, out_dir):
     ctx.close()
 
 
-def test_cluster_solve_survives_two_processes_competing_for_the_cus(tmp_path):
-    """Two processes, each launching 235-workgroup cluster solves on the same GPU: a grid that cannot become fully
-    resident in time gives up and the solve is redone with one launch per iteration.  Whichever way each solve went,
-    every result must equal the undisturbed one."""
+@pytest.mark.parametrize("n,voxels,solves", [(120_000, 3000, 60), (1_500_000, 30_000, 16)])
+def test_cluster_solve_survives_two_processes_competing_for_the_cus(tmp_path, n, voxels, solves):
+    """Two processes, each launching one-launch solves on the same GPU — 235 workgroups with the data resident on chip, and
+    256 workgroups STREAMING 1.5 M correspondences every iteration: a grid that cannot become fully resident in time gives
+    up and the solve is redone with one launch per iteration.  Whichever way each solve went, every result must equal the
+    undisturbed one."""
     import torch.multiprocessing as mp
-    mp.spawn(_cluster_contention_worker, args=(str(tmp_path),), nprocs=2, join=True)
+    mp.spawn(_cluster_contention_worker, args=(str(tmp_path), n, voxels, solves), nprocs=2, join=True)
     ctx = Context((0,))
-    ds = NdtDataset.from_planes(ctx, synth.ndt_planes(120_000, 3000), "f64")
+    ds = NdtDataset.from_planes(ctx, synth.ndt_planes(n, voxels), "f64")
     R, t, r = ds.solve6(np.eye(3), np.zeros(3), EXP, max_iterations=40)
     ds.close()
     ctx.close()
