@@ -95,18 +95,20 @@ def test_repeated_launches_are_bit_identical(ctx):
     ds.close()
 
 
-def test_ingestion_paths_agree_bit_for_bit(ctx):
-    """host planes / device planes (torch) / array-of-structures records → same tiled dataset."""
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_ingestion_paths_agree_bit_for_bit(ctx, dtype):
+    """host planes / device planes (torch) / array-of-structures records → same dataset (fp64: planar planes, fp32: the
+    1024-item tiles), and it reads back as what went in."""
     import torch
     if not torch.cuda.is_available():  # torch is plumbing for device memory here, not the product under test
         pytest.skip("torch cannot see the GPU on this box (libnos_hip can): device-plane ingestion not exercised")
     n = 20_011
     planes = synth.ndt_planes(n, 800)
     loss = ("exponential", 1.0, 1.0)
-    a = NdtDataset.from_planes(ctx, planes, "f64")
+    a = NdtDataset.from_planes(ctx, planes, dtype)
     want = a.accumulate6(R_TEST, T_TEST, loss)
     dev = torch.from_numpy(planes).cuda()
-    b = NdtDataset.from_device_planes(ctx, dev, "f64")
+    b = NdtDataset.from_device_planes(ctx, dev, dtype)
     assert np.array_equal(want, b.accumulate6(R_TEST, T_TEST, loss))
     # the reference's 304-byte Correspondence (MDM/types.h:11-26) with Eigen's column-major 3x3:
     # point @0, ndt.mean @128, ndt.sqrt_information @224
@@ -117,9 +119,12 @@ def test_ingestion_paths_agree_bit_for_bit(ctx):
         for j in range(3):
             rec[:, 28 + 3 * j + i] = planes[6 + 3 * i + j]
     offs = [0, 8, 16, 128, 136, 144] + [224 + 8 * (3 * j + i) for i in range(3) for j in range(3)]
-    c = NdtDataset.from_records(ctx, rec, 304, offs, "f64")
+    c = NdtDataset.from_records(ctx, rec, 304, offs, dtype)
     assert len(c) == n
     assert np.array_equal(want, c.accumulate6(R_TEST, T_TEST, loss))
+    from nonlinear_optimizer_for_slam_amd import api
+    back = api.download(a)
+    assert np.array_equal(back, planes if dtype == "f64" else planes.astype(np.float32).astype(np.float64))
     for d in (a, b, c):
         d.close()
 
