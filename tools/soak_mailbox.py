@@ -31,7 +31,7 @@ def worker(rank, world, name, rounds, out_dir):
 
 
 if __name__ == "__main__":
-    world = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+    world = min(5, int(sys.argv[1])) if len(sys.argv) > 1 else 3  # a GPU box allows at most 6 processes on its card
     rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
     name = "/nos_soak_%s" % uuid.uuid4().hex
     os.makedirs("gpurun_out", exist_ok=True)
