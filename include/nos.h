@@ -223,6 +223,14 @@ int nos_scan_sort_by_cell(nos_scan* scan, double cell_edge);
 int nos_scan_order(const nos_scan* scan, uint32_t* order_out);
 int nos_ndt_match(nos_ndt_map* map, nos_scan* scan, const double R[9], const double t[3],
                   int max_neighbors, int dtype, nos_dataset** out_ds, size_t* n_matches);
+/* Tail drop of the reference's solver classes for a matcher-written dataset.  The scalar 3-DoF class uses only the
+ * first floor(N/4)*4 entries of the correspondence vector (MDM/..._analytic_3dof.cc:33-36; the 6-DoF lines of
+ * the reference's results directory were captured from a revision that did the same), the SIMD classes floor(N/8)*8
+ * (MDM/..._analytic_simd.cc:46-51).  The reference's vector holds matches only, in scan order, nearest first
+ * (MDM/tests/simple_optimization_test.cc:320-340); here absent neighbours are zero records, so "drop the last k
+ * entries" is: clear the last n_drop NON-EMPTY records in slot order (on the device, asynchronously on the context's
+ * stream).  Flat NDT datasets on single-device contexts. */
+int nos_dataset_drop_last_matches(nos_dataset* ds, size_t n_drop);
 
 /* ---- voxel-indexed NDT datasets (additive; SURVEY.md §8d "voxel-indexed layout") ------
  * The reference copies the full NDT into every correspondence (MDM/types.h:23-26, :336 of the
@@ -262,6 +270,13 @@ typedef struct nos_map_stats nos_map_stats;
  * NOS_MAP_PROPER_SQRT_INFORMATION uses D^-1/2 * V^T, the true square root of the inverse
  * covariance, which is sign- and degenerate-subspace-invariant. */
 #define NOS_MAP_PROPER_SQRT_INFORMATION 1
+/* NOS_MAP_REFERENCE_EXACT: the harness formula with the reference BINARY's rounding — count / sum / moment accumulated per
+ * voxel sequentially in point order, Eigen::SelfAdjointEigenSolver<Matrix3d> restated step by step, multiply-adds fused
+ * exactly where the reference's -O2 -march=native x86-64 build fuses them (options "map_fma_mask", "map_eigen_version").
+ * The map then equals the one the reference's test drivers build bit for bit (tests/golden/ndt_reference_map.npz), and
+ * map build -> nos_ndt_match -> nos_ndt6_solve / nos_ndt3_solve reproduce the captured COST / iter lines of the reference's results directory.
+ * Voxels are listed in first-seen order (stats and voxel ids).  Not combinable with NOS_MAP_PROPER_SQRT_INFORMATION. */
+#define NOS_MAP_REFERENCE_EXACT 2
 int nos_ndt_map_build(nos_ctx* ctx, size_t n_points, const double* points_xyz,
                       double voxel_resolution, double search_radius_sq, int flags,
                       nos_ndt_map** out_map, nos_map_stats** out_stats);
@@ -270,6 +285,9 @@ size_t nos_map_stats_size(const nos_map_stats* stats);
  * counts [V], cells [V][3]. */
 int nos_map_stats_get(const nos_map_stats* stats, double* means_xyz, double* sqrt_infos,
                       unsigned char* valid, uint32_t* counts, int64_t* cells_xyz);
+/* NOS_MAP_REFERENCE_EXACT builds only: eigenvalues [V][3] ascending, before flooring; eigenvectors [V][9] row-major V
+ * (column k = eigenvector k) as Eigen returns them. */
+int nos_map_stats_get_eigen(const nos_map_stats* stats, double* eigenvalues, double* eigenvectors);
 int nos_map_stats_destroy(nos_map_stats* stats);
 
 /* ---- the hot path -------------------------------------------------------------
@@ -397,7 +415,8 @@ int nos_pgo_matvec(nos_pose_graph* pg, double lambda, const double* x, double* y
  * ---- experiment knobs ----------------------------------------------------------------
  * Read from the environment once, in nos_ctx_create (NOS_SC1, NOS_NT, NOS_FUSED, NOS_LM_FUSED, NOS_LM_WINDOW,
  * NOS_LM_SINGLE, NOS_LM_CLUSTER, NOS_POOL, NOS_TILE_LOG2, NOS_PLANE_SKEW, NOS_INGEST, NOS_INGEST_THREADS,
- * NOS_INDEXED_BPC, NOS_MATCH_DENSE, NOS_PGO_HOST_SCALARS, NOS_PGO_PRECOND, NOS_PGO_AGG); afterwards only through these setters (keys =
+ * NOS_INDEXED_BPC, NOS_MATCH_DENSE, NOS_PGO_HOST_SCALARS, NOS_PGO_PRECOND, NOS_PGO_AGG; option only: "map_fma_mask",
+ * "map_eigen_version"); afterwards only through these setters (keys =
  * the names in lower case without the prefix, e.g. "lm_cluster"; "ingest": 0 auto, 1 pack, 2 unpack;
  * "debug_cluster_abort": test hook, makes the next one-launch solve give up and fall back).  Nothing on the solve /
  * accumulate path reads the environment.

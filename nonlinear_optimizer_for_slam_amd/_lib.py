@@ -31,7 +31,7 @@ C_ABI_SYMBOLS = (
     "nos_ndt_dataset_create_from_records", "nos_reproj_dataset_create_from_records",
     "nos_dataset_download", "nos_ndt_map_create", "nos_ndt_map_destroy", "nos_ndt_map_size", "nos_scan_create",
     "nos_scan_destroy", "nos_scan_size", "nos_scan_sort_by_cell", "nos_scan_order", "nos_ndt_match", "nos_ndt_indexed_dataset_create", "nos_ndt_match_indexed", "nos_ndt_map_build", "nos_map_stats_size",
-    "nos_map_stats_get", "nos_map_stats_destroy", "nos_pgo_create", "nos_pgo_destroy", "nos_pgo_num_unknowns",
+    "nos_map_stats_get", "nos_map_stats_get_eigen", "nos_map_stats_destroy", "nos_dataset_drop_last_matches", "nos_pgo_create", "nos_pgo_destroy", "nos_pgo_num_unknowns",
     "nos_pgo_linearize", "nos_pgo_solve", "nos_pgo_retract", "nos_pgo_get_state", "nos_pgo_get_vector",
     "nos_pgo_matvec", "nos_dataset_destroy", "nos_dataset_size", "nos_dataset_dtype", "nos_dataset_stream_bytes",
     "nos_dataset_set_simd_class",
@@ -135,7 +135,9 @@ def _declare(lib):
     lib.nos_map_stats_size.restype = sz
     lib.nos_map_stats_get.argtypes = [vp, dp, dp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint32),
                                       ctypes.POINTER(ctypes.c_int64)]
+    lib.nos_map_stats_get_eigen.argtypes = [vp, dp, dp]
     lib.nos_map_stats_destroy.argtypes = [vp]
+    lib.nos_dataset_drop_last_matches.argtypes = [vp, sz]
     ip = ctypes.POINTER(ctypes.c_int32)
     lib.nos_pgo_create.argtypes = [vp, sz, dp, sz, ip, ip, dp, dp, ctypes.c_char_p, ctypes.c_char_p, c_void_pp]
     lib.nos_pgo_destroy.argtypes = [vp]

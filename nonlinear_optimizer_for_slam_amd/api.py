@@ -315,6 +315,11 @@ class NdtDataset(_Dataset):
     _create_dev = "nos_ndt_dataset_create_from_device"
     _create_rec = "nos_ndt_dataset_create_from_records"
 
+    def drop_last_matches(self, n_drop):
+        """Clear the last n_drop non-empty records (slot order) of a matcher-written dataset: the tail drop of the
+        reference's solver classes, e.g. n_matches % 4 for the scalar 3-DoF class (nos_dataset_drop_last_matches)."""
+        check(self._lib.nos_dataset_drop_last_matches(self._h, int(n_drop)), "nos_dataset_drop_last_matches")
+
     def accumulate6(self, R, t, loss=None):
         R = _dvec(R, 9)
         t = _dvec(t, 3)
@@ -483,19 +488,25 @@ class NdtMap:
         ctx._adopt(self)
 
     @classmethod
-    def build(cls, ctx, points, voxel_resolution=1.0, search_radius_sq=1.0, proper_sqrt_information=True):
+    def build(cls, ctx, points, voxel_resolution=1.0, search_radius_sq=1.0, proper_sqrt_information=True,
+              reference_exact=False):
         """Construct the map from raw points [n,3] on the GPU (nos_ndt_map_build, the reference's
         UpdateNdtMap).  → (NdtMap, stats dict with means, sqrt_infos, valid, counts, cells).
 
         proper_sqrt_information=True (default) stores D^-1/2 V^T, the true square root of the inverse
         covariance; False reproduces the harness formula D^-1/2 V, which is only meaningful when V happens
-        to be symmetric (include/nos.h)."""
+        to be symmetric (include/nos.h).
+
+        reference_exact=True (NOS_MAP_REFERENCE_EXACT): the harness formula with the reference binary's rounding —
+        sequential per-voxel accumulation, Eigen's SelfAdjointEigenSolver restated, the reference build's fused
+        multiply-adds; voxels in first-seen order; the stats dict also carries eigvals / eigvecs."""
         pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
         h = ctypes.c_void_p()
         hs = ctypes.c_void_p()
         lib = ctx._lib
+        flags = 2 if reference_exact else int(bool(proper_sqrt_information))
         check(lib.nos_ndt_map_build(ctx.handle, pts.shape[0], _dp(pts), ctypes.c_double(voxel_resolution),
-                                    ctypes.c_double(search_radius_sq), int(bool(proper_sqrt_information)),
+                                    ctypes.c_double(search_radius_sq), flags,
                                     ctypes.byref(h), ctypes.byref(hs)),
               "nos_ndt_map_build")
         V = int(lib.nos_map_stats_size(hs))
@@ -507,14 +518,21 @@ class NdtMap:
         check(lib.nos_map_stats_get(hs, _dp(means), _dp(S), valid.ctypes.data_as(ctypes.c_char_p),
                                     counts.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)),
                                     cells.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))), "nos_map_stats_get")
+        stats = {"means": means, "sqrt_infos": S.reshape(V, 3, 3), "valid": valid.astype(bool),
+                 "counts": counts, "cells": cells}
+        if reference_exact:
+            evals = np.zeros((V, 3))
+            evecs = np.zeros((V, 9))
+            check(lib.nos_map_stats_get_eigen(hs, _dp(evals), _dp(evecs)), "nos_map_stats_get_eigen")
+            stats["eigvals"] = evals
+            stats["eigvecs"] = evecs.reshape(V, 3, 3)
         lib.nos_map_stats_destroy(hs)
         self = cls.__new__(cls)
         self._ctx = ctx
         self._lib = lib
         self._h = h
         ctx._adopt(self)
-        return self, {"means": means, "sqrt_infos": S.reshape(V, 3, 3), "valid": valid.astype(bool),
-                      "counts": counts, "cells": cells}
+        return self, stats
 
     def __len__(self):
         return int(self._lib.nos_ndt_map_size(self._h))

@@ -208,6 +208,30 @@ __global__ __launch_bounds__(256) void match_kernel(MapView map, const double* _
   if ((threadIdx.x & (kWave - 1)) == 0 && s > 0) atomicAdd(n_matches, (unsigned long long)s);
 }
 
+// Clears the last n_drop NON-EMPTY records of a matcher-written NDT dataset, in slot order: what dropping the tail of
+// the reference's compacted correspondence vector does (floor(N/4)*4 of the scalar 3-DoF class,
+// MDM/mahalanobis_distance_minimizer_analytic_3dof.cc:33-36).  A record is empty when its sqrt-information is all zero.
+// One wave walks backwards from the end, 64 slots at a time; n_drop is small (< 8), so it touches the tail only.
+template <typename T>
+__global__ __launch_bounds__(64) void drop_last_matches_kernel(T* __restrict__ data, TiledLayout L, uint64_t n_drop) {
+  const int lane = threadIdx.x;
+  uint64_t remaining = n_drop;
+  for (uint64_t pos = L.n; remaining > 0 && pos > 0; pos = pos > 64 ? pos - 64 : 0) {
+    const bool in_range = pos > uint64_t(lane);
+    const uint64_t i = in_range ? pos - 1 - uint64_t(lane) : 0;
+    const uint64_t off = (i >> L.tile_shift) * L.tile_stride + (i & L.tile_mask);
+    bool nonempty = false;
+    if (in_range)
+      for (int f = 6; f < 15; ++f) nonempty = nonempty || data[off + uint64_t(f) * L.field_stride] != T(0);
+    const unsigned long long mask = __ballot(nonempty);
+    const uint64_t before = uint64_t(__popcll(mask & ((1ull << lane) - 1ull)));  // non-empty slots nearer to the end
+    if (nonempty && before < remaining)
+      for (int f = 0; f < 15; ++f) data[off + uint64_t(f) * L.field_stride] = T(0);
+    const uint64_t found = uint64_t(__popcll(mask));
+    remaining -= found < remaining ? found : remaining;
+  }
+}
+
 // tiled dataset → planar host-order planes (diagnostics / tests)
 template <typename SRC>
 __global__ __launch_bounds__(256) void untile_kernel(const SRC* __restrict__ src, int n_fields, TiledLayout L,

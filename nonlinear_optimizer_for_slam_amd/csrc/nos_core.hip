@@ -1510,7 +1510,9 @@ const OptionEntry kOptions[] = {
     {"tile_log2", &nosd::Settings::tile_log2}, {"ingest", &nosd::Settings::ingest},
     {"ingest_threads", &nosd::Settings::ingest_threads}, {"indexed_bpc", &nosd::Settings::indexed_bpc},
     {"match_dense", &nosd::Settings::match_dense}, {"pgo_host_scalars", &nosd::Settings::pgo_host_scalars},
-    {"pgo_precond", &nosd::Settings::pgo_precond}, {"pgo_agg", &nosd::Settings::pgo_agg}, {"debug_cluster_abort", &nosd::Settings::debug_cluster_abort},
+    {"pgo_precond", &nosd::Settings::pgo_precond}, {"pgo_agg", &nosd::Settings::pgo_agg},
+    {"map_fma_mask", &nosd::Settings::map_fma_mask}, {"map_eigen_version", &nosd::Settings::map_eigen_version},
+    {"debug_cluster_abort", &nosd::Settings::debug_cluster_abort},
 };
 }  // namespace
 

@@ -124,6 +124,7 @@ struct DeviceSlot {
 }  // namespace nosd
 
 namespace nosd {
+constexpr int kMapReferenceFmaMask = (4 | 8 | 16 | 32) | ((1 | 4 | 8 | 32 | 256) << 8) | (0x1ff << 17);
 // Experiment / test knobs.  Read from the environment ONCE, when the context is created (nos_ctx_create), and
 // changed afterwards only through nos_ctx_set_option: nothing on the solve / accumulate path calls getenv().
 struct Settings {
@@ -144,6 +145,11 @@ struct Settings {
   int pgo_host_scalars = 0;  // NOS_PGO_HOST_SCALARS
   int pgo_precond = 1;       // NOS_PGO_PRECOND     0 block-Jacobi only, 1 two-level (rigid-motion coarse space)
   int pgo_agg = 48;          // NOS_PGO_AGG         poses per aggregate of the coarse level
+  // NOS_MAP_REFERENCE_EXACT builds (mapexact_kernels.hpp): which multiply-adds are fused and which Eigen release's
+  // deflation test / shift guard is followed.  Defaults = what reproduces the reference's captured x86-64 runs;
+  // map_fma_mask = 0 follows the aarch64 captures (tests/test_reference_ndt_runs.py).
+  int map_fma_mask = kMapReferenceFmaMask;
+  int map_eigen_version = 34;
   int debug_cluster_abort = 0;  // test hook (no environment name): the next one-launch solve finds `abort` raised
 };
 }  // namespace nosd

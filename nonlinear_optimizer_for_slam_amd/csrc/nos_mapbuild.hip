@@ -8,12 +8,22 @@
 using namespace nosd;
 
 struct nos_map_stats {
-  std::vector<double> means;            // [V][3] voxel order = ascending packed (ix, iy, iz)
+  std::vector<double> means;            // [V][3] voxel order = ascending packed (ix, iy, iz); reference-exact mode: first seen
   std::vector<double> sqrt_infos;       // [V][9]
   std::vector<unsigned char> valid;     // [V]
   std::vector<uint32_t> counts;         // [V]
   std::vector<int64_t> cells;           // [V][3] integer voxel coordinates
+  std::vector<double> evals;            // [V][3] un-floored eigenvalues           (reference-exact mode only)
+  std::vector<double> evecs;            // [V][9] row-major eigenvector matrix V   (reference-exact mode only)
 };
+
+namespace nosd {
+// nos_mapexact.hip (compiled with -ffp-contract=off)
+hipError_t launch_map_exact(const double* px, const double* py, const double* pz, const uint32_t* sorted_idx,
+                            const uint32_t* seg_offset, const uint32_t* seg_count, uint32_t n_voxels, int fma_mask,
+                            int eigen_version, double* acc, double* mean, double* sqrt_info, unsigned char* valid,
+                            double* evals, double* evecs, uint32_t* first_idx, hipStream_t stream);
+}  // namespace nosd
 
 extern "C" {
 
@@ -114,6 +124,16 @@ int nos_map_stats_get(const nos_map_stats* stats, double* means_xyz, double* sqr
   return NOS_OK;
 }
 
+int nos_map_stats_get_eigen(const nos_map_stats* stats, double* eigenvalues, double* eigenvectors) {
+  if (!stats) return fail(NOS_ERR_INVALID_ARGUMENT, "stats is NULL");
+  if (stats->evals.empty() && !stats->counts.empty())
+    return fail(NOS_ERR_UNSUPPORTED, "eigen-decompositions are kept by NOS_MAP_REFERENCE_EXACT builds only");
+  const size_t V = stats->counts.size();
+  if (eigenvalues) memcpy(eigenvalues, stats->evals.data(), V * 3 * sizeof(double));
+  if (eigenvectors) memcpy(eigenvectors, stats->evecs.data(), V * 9 * sizeof(double));
+  return NOS_OK;
+}
+
 int nos_ndt_map_build(nos_ctx* ctx, size_t n_points, const double* points_xyz, double voxel_resolution,
                       double search_radius_sq, int flags, nos_ndt_map** out_map, nos_map_stats** out_stats) {
   nosd::CtxGuard guard_(ctx);  // one solve / accumulate / create at a time per context
@@ -123,6 +143,9 @@ int nos_ndt_map_build(nos_ctx* ctx, size_t n_points, const double* points_xyz, d
   if (ctx->slots.size() != 1) return fail(NOS_ERR_UNSUPPORTED, "map build needs a single-device context");
   if (!(voxel_resolution > 0.0) || !std::isfinite(voxel_resolution)) return fail(NOS_ERR_INVALID_ARGUMENT, "bad voxel resolution");
   if (n_points >= 0xFFFFFFFFull) return fail(NOS_ERR_UNSUPPORTED, "too many points for one build");
+  const bool exact = (flags & NOS_MAP_REFERENCE_EXACT) != 0;
+  if (exact && (flags & NOS_MAP_PROPER_SQRT_INFORMATION))
+    return fail(NOS_ERR_INVALID_ARGUMENT, "NOS_MAP_REFERENCE_EXACT reproduces the harness formula D^-1/2 V; it cannot be combined with NOS_MAP_PROPER_SQRT_INFORMATION");
   nos_scan* scan = nullptr;
   int rc = nos_scan_create(ctx, n_points, points_xyz, &scan);  // [n][3] → 3 planes on the device
   if (rc != NOS_OK) return rc;
@@ -164,12 +187,21 @@ int nos_ndt_map_build(nos_ctx* ctx, size_t n_points, const double* points_xyz, d
   }
   std::unique_ptr<nos_map_stats> stats(new (std::nothrow) nos_map_stats());
   if (!stats) e = hipErrorOutOfMemory;
-  double *d_mean = nullptr, *d_S = nullptr;
+  double *d_mean = nullptr, *d_S = nullptr, *d_acc = nullptr, *d_evals = nullptr, *d_evecs = nullptr;
   unsigned char* d_valid = nullptr;
+  uint32_t* d_first = nullptr;
   if (e == hipSuccess) e = buf.alloc(&d_mean, size_t(V) * 3);
   if (e == hipSuccess) e = buf.alloc(&d_S, size_t(V) * 9);
   if (e == hipSuccess) e = buf.alloc(&d_valid, size_t(V));
-  if (e == hipSuccess && V > 0) {
+  if (e == hipSuccess && exact) {
+    e = buf.alloc(&d_acc, size_t(V) * 12);
+    if (e == hipSuccess) e = buf.alloc(&d_evals, size_t(V) * 3);
+    if (e == hipSuccess) e = buf.alloc(&d_evecs, size_t(V) * 9);
+    if (e == hipSuccess) e = buf.alloc(&d_first, size_t(V));
+    if (e == hipSuccess)
+      e = launch_map_exact(px, py, pz, idx_sorted, offsets, counts, V, ctx->settings.map_fma_mask,
+                           ctx->settings.map_eigen_version, d_acc, d_mean, d_S, d_valid, d_evals, d_evecs, d_first, st);
+  } else if (e == hipSuccess && V > 0) {
     const nos::MapBuildParams prm{5, 0.01, 0.01, (flags & NOS_MAP_PROPER_SQRT_INFORMATION) ? 1 : 0};
     const unsigned blocks = unsigned((size_t(V) * nos::kWave + 255) / 256);
     hipLaunchKernelGGL(nos::voxel_stats_kernel, dim3(blocks), dim3(256), 0, st, px, py, pz, idx_sorted, offsets, counts, V,
@@ -177,6 +209,12 @@ int nos_ndt_map_build(nos_ctx* ctx, size_t n_points, const double* points_xyz, d
     e = hipGetLastError();
   }
   std::vector<uint64_t> h_keys(V);
+  std::vector<uint32_t> h_first;
+  if (e == hipSuccess && exact) {
+    stats->evals.resize(size_t(V) * 3);
+    stats->evecs.resize(size_t(V) * 9);
+    h_first.resize(V);
+  }
   if (e == hipSuccess) {
     stats->means.resize(size_t(V) * 3);
     stats->sqrt_infos.resize(size_t(V) * 9);
@@ -190,6 +228,11 @@ int nos_ndt_map_build(nos_ctx* ctx, size_t n_points, const double* points_xyz, d
     if (e == hipSuccess) e = hipMemcpyAsync(stats->valid.data(), d_valid, V, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipMemcpyAsync(stats->counts.data(), counts, size_t(V) * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipMemcpyAsync(h_keys.data(), uniq, size_t(V) * sizeof(uint64_t), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && exact) {
+      e = hipMemcpyAsync(stats->evals.data(), d_evals, size_t(V) * 3 * sizeof(double), hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess) e = hipMemcpyAsync(stats->evecs.data(), d_evecs, size_t(V) * 9 * sizeof(double), hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess) e = hipMemcpyAsync(h_first.data(), d_first, size_t(V) * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
   }
   nos_scan_destroy(scan);
@@ -200,6 +243,25 @@ int nos_ndt_map_build(nos_ctx* ctx, size_t n_points, const double* points_xyz, d
     stats->cells[3 * size_t(v) + 0] = int64_t((h_keys[v] >> 42) & 0x1FFFFFull) - bias;
     stats->cells[3 * size_t(v) + 1] = int64_t((h_keys[v] >> 21) & 0x1FFFFFull) - bias;
     stats->cells[3 * size_t(v) + 2] = int64_t(h_keys[v] & 0x1FFFFFull) - bias;
+  }
+  if (exact && V > 1) {
+    // the reference's map lists its voxels as they were first seen (our restatement of its unordered_map walk): voxel
+    // ids — the matcher's tie-break — then agree with the reference-exact CPU restatement's
+    std::vector<uint32_t> perm(V);
+    for (uint32_t v = 0; v < V; ++v) perm[v] = v;
+    std::sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return h_first[a] < h_first[b]; });
+    auto permute = [&](auto& vec, size_t width) {
+      auto old = vec;
+      for (uint32_t v = 0; v < V; ++v)
+        for (size_t k = 0; k < width; ++k) vec[size_t(v) * width + k] = old[size_t(perm[v]) * width + k];
+    };
+    permute(stats->means, 3);
+    permute(stats->sqrt_infos, 9);
+    permute(stats->valid, 1);
+    permute(stats->counts, 1);
+    permute(stats->cells, 3);
+    permute(stats->evals, 3);
+    permute(stats->evecs, 9);
   }
   rc = nos_ndt_map_create(ctx, V, stats->means.data(), stats->sqrt_infos.data(), stats->valid.data(), search_radius_sq,
                           out_map);

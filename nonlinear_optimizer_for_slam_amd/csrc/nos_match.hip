@@ -275,6 +275,25 @@ int nos_ndt_match(nos_ndt_map* map, nos_scan* scan, const double R[9], const dou
   return NOS_OK;
 }
 
+int nos_dataset_drop_last_matches(nos_dataset* ds, size_t n_drop) {
+  nosd::CtxGuard guard_(ds ? ds->ctx : nullptr);  // one solve / accumulate / create at a time per context
+  if (!ds) return fail(NOS_ERR_INVALID_ARGUMENT, "dataset is NULL");
+  if (ds->kind != kKindNdt) return fail(NOS_ERR_WRONG_KIND, "flat NDT datasets only");
+  if (ds->shards.size() != 1) return fail(NOS_ERR_UNSUPPORTED, "single-device datasets only");
+  if (n_drop == 0 || ds->n == 0) return NOS_OK;
+  Shard& sh = ds->shards[0];
+  DeviceSlot& slot = ds->ctx->slots[sh.slot];
+  NOS_HIP_CHECK(hipSetDevice(slot.device));
+  if (ds->dtype == NOS_F64)
+    hipLaunchKernelGGL((nos::drop_last_matches_kernel<double>), dim3(1), dim3(64), 0, slot.stream,
+                       static_cast<double*>(sh.data), sh.layout, uint64_t(n_drop));
+  else
+    hipLaunchKernelGGL((nos::drop_last_matches_kernel<float>), dim3(1), dim3(64), 0, slot.stream,
+                       static_cast<float*>(sh.data), sh.layout, uint64_t(n_drop));
+  NOS_HIP_CHECK(hipGetLastError());
+  return NOS_OK;  // stream order: every later launch on this context sees the cleared records
+}
+
 int nos_dataset_download(nos_dataset* ds, double* const planes[]) {
   nosd::CtxGuard guard_(ds ? ds->ctx : nullptr);  // one solve / accumulate / create at a time per context
   if (!ds || !planes) return fail(NOS_ERR_INVALID_ARGUMENT, "NULL argument");

@@ -20,7 +20,8 @@ def _quat_vec_norm(R):
 
 
 def scan_to_map(ctx, ndt_map, scan, initial_pose=None, loss=("exponential", 1.0, 1.0), options=None,
-                max_outer_iterations=10, dof=6, dtype="f64", on_solve=None, indexed=False):
+                max_outer_iterations=10, dof=6, dtype="f64", on_solve=None, indexed=False, keep_multiple=None,
+                device_loop=True):
     """ndt_map: api.NdtMap, scan: api.Scan.  → (Pose, list of per-round dicts, outer_iter) — outer_iter as the
     reference prints it (index of the round that met the stopping test, or max_outer_iterations).
 
@@ -28,13 +29,17 @@ def scan_to_map(ctx, ndt_map, scan, initial_pose=None, loss=("exponential", 1.0,
     the voxel-indexed layout — 2-3x less memory traffic per LM iteration for large scans (sort the scan by cell first:
     api.Scan(..., sort_cell=...)); same sums, same pose.
 
+    keep_multiple=k: every round uses only the first floor(N/k)*k of its N matches, as the reference's classes do on their
+    correspondence vector (k = 4: scalar 3-DoF class, MDM/..._analytic_3dof.cc:33-36, and the revision of the 6-DoF class
+    behind results/*.txt; k = 8: the SIMD classes) — done on the device (nos_dataset_drop_last_matches).
+
     on_solve(round, report, n_matches) is called after every inner Solve (e.g. to print the
     reference's `COST: ..., iter: ...` lines)."""
     pose = Pose() if initial_pose is None else Pose(initial_pose.R, initial_pose.t)
     last = Pose(pose.R, pose.t)
     options = options or Options()
     solver = (MahalanobisDistanceMinimizerHip3DOF if dof == 3 else MahalanobisDistanceMinimizerHip)(
-        device_ids=ctx.device_ids, dtype=dtype)
+        device_ids=ctx.device_ids, dtype=dtype, device_loop=device_loop)
     solver.SetLossFunction(loss)
     rounds = []
     outer = 0
@@ -43,6 +48,8 @@ def scan_to_map(ctx, ndt_map, scan, initial_pose=None, loss=("exponential", 1.0,
             dataset, n_matches = ndt_map.match_indexed(scan, pose.R, pose.t, 2, dtype, sort_by_voxel=False)
         else:
             dataset, n_matches = ndt_map.match(scan, pose.R, pose.t, 2, dtype)
+            if keep_multiple:
+                dataset.drop_last_matches(n_matches % int(keep_multiple))
         try:
             if not solver.SolveDataset(options, dataset, pose):
                 raise RuntimeError("SolveDataset failed (status %d)" % solver.report.status)
@@ -57,4 +64,6 @@ def scan_to_map(ctx, ndt_map, scan, initial_pose=None, loss=("exponential", 1.0,
         if np.linalg.norm(dt) < 1e-5 and _quat_vec_norm(dR) < 1e-5:
             break
         last = Pose(pose.R, pose.t)
+    else:
+        outer = max_outer_iterations  # never met the stopping test: the reference's loop variable ends at the bound
     return pose, rounds, outer

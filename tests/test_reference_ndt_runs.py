@@ -182,3 +182,113 @@ def test_hip_solver_classes_reproduce_the_captured_run(oracle, points, ndt_map, 
 
     R, t, rounds, outer = scene.captured_run_icp(solve, ndt_map, local, stride=4)
     _check_run(oracle, name, R, t, rounds, outer)
+
+
+# ------------------------------------------------------------- GPU, every stage on the device (rows f2 / f4 pinned)
+
+def _cantor_keys(cells):
+    """ComputeVoxelKey (MDM/tests/simple_optimization_test.cc:283-294) of integer voxel coordinates."""
+    return scene.voxel_keys(cells.astype(np.float64) + 0.5, 1.0)
+
+
+@pytest.mark.gpu
+def test_gpu_reference_exact_map_equals_the_reference_map_bit_for_bit(ctx, points):
+    """nos_ndt_map_build(NOS_MAP_REFERENCE_EXACT) on the reference's 954 605 room points against
+    tests/golden/ndt_reference_map.npz — the map that reproduces the reference's captured runs: same 96 voxels in the
+    same order, counts, means, eigenvalues, eigenvectors and sqrt_information of EVERY voxel bit for bit (the degenerate
+    floor / wall patches, whose eigenvectors are decided by rounding noise, included)."""
+    from nonlinear_optimizer_for_slam_amd import api
+    fix = np.load(os.path.join(HERE, "golden", "ndt_reference_map.npz"))
+    gm, got = api.NdtMap.build(ctx, points, 1.0, 1.0, reference_exact=True)
+    assert len(gm) == KNOWN["scene_counts"]["ndt_voxels"]["value"] == got["means"].shape[0]
+    assert np.array_equal(_cantor_keys(got["cells"]), fix["keys"])
+    assert np.array_equal(got["counts"].astype(np.int64), fix["count"].astype(np.int64))
+    assert np.array_equal(got["valid"], fix["valid"])
+    for k in ("means", "eigvals", "eigvecs", "sqrt_infos"):
+        assert np.array_equal(got[k], fix[k]), (k, np.abs(got[k] - fix[k]).max())
+    gm.close()
+    # the same build with no fused multiply-add equals the CPU restatement's unfused map (the aarch64 captures' map)
+    with ctx.options(map_fma_mask=0):
+        gm0, got0 = api.NdtMap.build(ctx, points, 1.0, 1.0, reference_exact=True)
+    want0 = scene.build_ndt_map_eigen(points, 1.0, fma_mask=0)
+    for k in ("means", "eigvals", "eigvecs", "sqrt_infos"):
+        assert np.array_equal(got0[k], want0[k]), k
+    assert not np.array_equal(got0["sqrt_infos"], got["sqrt_infos"])
+    gm0.close()
+
+
+@pytest.mark.gpu
+def test_gpu_reference_exact_map_on_ragged_voxels(ctx):
+    """Voxels of 1 … a few thousand points, too few points, thin slivers, negative coordinates: the GPU build equals the
+    CPU restatement bit for bit, for both Eigen release semantics and two contraction settings."""
+    from nonlinear_optimizer_for_slam_amd import api
+    rng = np.random.default_rng(7)
+    parts = [rng.uniform(0, 1, size=(n, 3)) * s + o for n, s, o in (
+        (4, 1.0, (10.0, 0, 0)), (5, 1.0, (-3.0, 2.0, 0.0)), (3000, (1.0, 1.0, 0.02), (2.0, -7.0, 1.0)),
+        (700, 0.05, (-5.0, 2.0, 1.0)), (64, 1.0, (0.0, 0.0, 0.0)), (65, 1.0, (1.0, 0.0, -1.0)), (1, 1.0, (-9.0, -9.0, -9.0)),
+        (5000, (1.0, 0.3, 1.0), (4.0, 4.0, 4.0)))]
+    pts = np.concatenate(parts)
+    pts = pts[rng.permutation(pts.shape[0])]
+    for version in (33, 34):
+        for mask in (scene.REFERENCE_FMA_MASK, 0):
+            want = scene.build_ndt_map_eigen(pts, 1.0, version=version, fma_mask=mask)
+            with ctx.options(map_fma_mask=mask, map_eigen_version=version):
+                gm, got = api.NdtMap.build(ctx, pts, 1.0, 1.0, reference_exact=True)
+            assert np.array_equal(_cantor_keys(got["cells"]), want["keys"])
+            assert np.array_equal(got["counts"].astype(np.int64), want["count"].astype(np.int64))
+            assert np.array_equal(got["valid"], want["valid"]) and 0 < int(want["valid"].sum()) < len(want["valid"])
+            for k in ("means", "eigvals", "eigvecs", "sqrt_infos"):
+                assert np.array_equal(got[k], want[k]), (k, version, mask)
+            assert len(gm) == int(want["valid"].sum())
+            gm.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("device_loop", [True, False])
+@pytest.mark.parametrize("name", sorted(RUNS))
+def test_whole_gpu_pipeline_reproduces_the_captured_run(ctx, oracle, points, name, device_loop):
+    """Every stage of the reference's test driver on the GPU: UpdateNdtMap → nos_ndt_map_build(NOS_MAP_REFERENCE_EXACT),
+    MatchPointCloud → nos_ndt_match, the class's floor(N/4)*4 tail drop → nos_dataset_drop_last_matches, Solve →
+    nos_ndt6_solve / nos_ndt3_solve through the drop-in classes' SolveDataset.  Only the room points and the scan go in;
+    the 17 COST / iter lines, the outer_iter counts and the final poses of results/*.txt come out as printed."""
+    from nonlinear_optimizer_for_slam_amd import api, pipeline
+    local, _, _ = scene.captured_run_scan(points, name)
+    dof = scene.CAPTURED_RUNS[name][3]
+    gm, _ = api.NdtMap.build(ctx, points, 1.0, 1.0, reference_exact=True)
+    sc = api.Scan(ctx, local)
+    pose, rounds, outer = pipeline.scan_to_map(ctx, gm, sc, loss=LOSS, dof=dof, keep_multiple=4, device_loop=device_loop)
+    _check_run(oracle, name, pose.R, pose.t, [(r["printed_cost"], r["iterations"], r["matches"]) for r in rounds], outer)
+    sc.close()
+    gm.close()
+
+
+@pytest.mark.gpu
+def test_drop_last_matches_clears_exactly_the_tail_of_the_compacted_list(ctx):
+    """nos_dataset_drop_last_matches against compact_correspondences on a scan where many points have 0 or 1 match (so
+    the last non-empty records are far apart), both element types, k = 0 … 9."""
+    from nonlinear_optimizer_for_slam_amd import api
+    rng = np.random.default_rng(5)
+    V, n = 400, 3000
+    means = rng.uniform(-8, 8, size=(V, 3))
+    S = rng.normal(size=(V, 3, 3))
+    pts = rng.uniform(-9, 9, size=(n, 3))
+    pts[-400:] += 100.0  # a long unmatched tail: the walk back has to cross several 64-slot steps
+    m = api.NdtMap(ctx, means, S, None, 1.0)
+    sc = api.Scan(ctx, pts)
+    for dtype in ("f64", "f32"):
+        ds, n_matches = m.match(sc, np.eye(3), np.zeros(3), 2, dtype)
+        full = api.download(ds)
+        ds.close()
+        nonempty = np.nonzero(np.any(full[6:15] != 0, axis=0))[0]
+        assert nonempty.size == n_matches and 100 < n_matches < 2 * n - 800
+        for k in (0, 1, 3, 7, 9):
+            ds, _ = m.match(sc, np.eye(3), np.zeros(3), 2, dtype)
+            ds.drop_last_matches(k)
+            got = api.download(ds)
+            want = full.copy()
+            if k:
+                want[:, nonempty[-k:]] = 0.0
+            assert np.array_equal(got, want), (dtype, k)
+            ds.close()
+    sc.close()
+    m.close()
