@@ -611,11 +611,17 @@ struct VecOf<double, 1> { using type = double; };
 template <>
 struct VecOf<double, 2> { using type = double __attribute__((ext_vector_type(2))); };
 template <>
+struct VecOf<double, 4> { using type = double __attribute__((ext_vector_type(4))); };  // two 16-byte loads
+template <>
+struct VecOf<double, 8> { using type = double __attribute__((ext_vector_type(8))); };
+template <>
 struct VecOf<float, 1> { using type = float; };
 template <>
 struct VecOf<float, 2> { using type = float __attribute__((ext_vector_type(2))); };
 template <>
 struct VecOf<float, 4> { using type = float __attribute__((ext_vector_type(4))); };
+template <>
+struct VecOf<float, 8> { using type = float __attribute__((ext_vector_type(8))); };
 
 template <typename T, int N, bool NT>
 __device__ __forceinline__ void load_items(const T* p, T (&dst)[N]) {
@@ -983,8 +989,149 @@ __device__ __forceinline__ bool lm_prologue(const FusedFinal& fin, Params& P) {
   return false;
 }
 
-// Loop body after the sums are known (one lane).  `tot` holds the NOUT sums; the new state goes to device memory
-// for the next launch and, if `entry_host` is set, to the pinned log entry the host is waiting for.
+// ---------------------------------------------------------------- the loop body on the device: one wave, data in LDS
+//
+// nos_host::LmAdvance6 / LmAdvance3 (csrc/host/nos_lm.hpp; the reference's loop body, MDM/..._analytic_simd.cc:78-102) as
+// ONE WAVE executes it in every device form of the loop (launch per iteration, stand-alone step kernel, single workgroup,
+// one-launch resident / streamed).  Round 2 ran that function inlined on one lane; unrolled for ILP it wanted ≈ 230
+// VGPRs (a 6x6 system, its factor, the sums, the state), which pinned every kernel that contained it at the 256-register
+// ceiling and made the streaming kernels spill around it.  Here the damped normal equations live in LDS, ONE element per
+// lane — lane (i, k) of a 6 x 7 arrangement owns a_ik (k <= i) or the right-hand side (k = 6) — and the right-looking LDLᵀ
+// with reciprocal pivots, the forward and the backward substitution of nos_host::SolveLdlt run across the lanes: the same
+// operations on every element in the same order (every update an explicit fma), so the result is that function's to the
+// bit wherever the compiler contracted it the same way.  Lane 0 then does the O(1) rest (pose update, tests, λ) with the
+// very functions the host loop uses.  A real (noinline) function: ≈ 40 VGPRs, none of them the streaming loop's.
+// All lanes of the calling wave must be active; `lmd`, `tot`, `work` are LDS; contains wave-level synchronisation only.
+using LdsDouble = __attribute__((address_space(3))) double;
+using LdsLmDevice = __attribute__((address_space(3))) LmDevice;
+constexpr int kLmWorkDoubles = 6 * 8;
+
+__device__ __forceinline__ void wave_sync_lds() {
+  // LDS instructions of one wave execute in issue order; this only keeps the compiler from moving accesses across
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int NOUT>
+__device__ __attribute__((noinline)) void lm_step_wave(const LdsDouble* tot, LdsLmDevice* lmd, LdsDouble* work) {
+  constexpr int N = NOUT == 28 ? 6 : 3;
+  constexpr int W = 8;  // row pitch of the work matrix: columns 0..N-1 lower triangle, column N right-hand side
+  const int lane = threadIdx.x & (kWave - 1);
+  const int i = lane / (N + 1), k = lane % (N + 1);
+  const bool in_sys = lane < N * (N + 1);
+  const bool lower = in_sys && k <= i;  // (k < N follows)
+  const bool rhs = in_sys && k == N;
+  double val = 0.0;
+  if (lower) {
+    val = tot[k * N - (k * (k - 1)) / 2 + (i - k)];  // H(k, i) of the upper triangle, row-major
+    if (i == k) val *= 1.0 + lmd->st.lambda;         // H_kk *= 1 + lambda
+  }
+  if (rhs) val = -tot[N * (N + 1) / 2 + i];
+  if (lower || rhs) work[i * W + k] = val;
+  wave_sync_lds();
+  bool ok = true;
+  double inv_i = 0.0, l_col = 0.0;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const double d = work[j * W + j];                 // the same word in every lane
+    if (!(d > 0.0) || !(d <= DBL_MAX)) {              // wave-uniform
+      ok = false;
+      break;
+    }
+    const double inv = 1.0 / d;
+    if (rhs && i == j) inv_i = inv;
+    if (in_sys && i > j) {
+      const double l = work[i * W + j] * inv;         // l_i = a_ij / d_j
+      if (k == j) l_col = l;                          // this lane's entry of L, stored after the loop
+      if (k > j && (k <= i || rhs)) {                 // a_ik -= l_i a_kj (j < k <= i);  y_i -= l_i y_j (k = N)
+        const double other = rhs ? work[j * W + N] : work[k * W + j];
+        val = __builtin_fma(-l, other, val);
+        work[i * W + k] = val;                        // never a word this step reads (column j, y_j)
+      }
+    }
+    wave_sync_lds();
+  }
+  if (ok) {
+    if (in_sys && k < i) work[i * W + k] = l_col;     // L below the diagonal
+    if (rhs) {
+      val *= inv_i;                                    // x = D^-1 y
+      work[i * W + N] = val;
+    }
+    wave_sync_lds();
+#pragma unroll
+    for (int c = N - 1; c > 0; --c) {                  // x_i -= L_ci x_c  (i < c)
+      if (rhs && i < c) {
+        val = __builtin_fma(-work[c * W + i], work[c * W + N], val);
+        work[i * W + N] = val;
+      }
+      wave_sync_lds();
+    }
+  }
+  if (lane == 0) {
+    const nos_host::LmSettings settings = {lmd->settings.max_iterations, lmd->settings.gradient_tolerance,
+                                           lmd->settings.parameter_tolerance, lmd->settings.float_schedule};
+    const double cost = tot[NOUT - 1];
+    lmd->st.cost = cost;
+    if (!ok) {
+      lmd->st.ok = 0;
+      lmd->st.done = 1;
+    } else {
+      double step[N], g[N];
+#pragma unroll
+      for (int r = 0; r < N; ++r) {
+        step[r] = work[r * W + N];
+        g[r] = tot[N * (N + 1) / 2 + r];
+      }
+      if constexpr (N == 6) {
+        lmd->st.t[0] += step[0];
+        lmd->st.t[1] += step[1];
+        lmd->st.t[2] += step[2];
+        nos_host::Quat q;
+        q.w = lmd->st.q.w, q.x = lmd->st.q.x, q.y = lmd->st.q.y, q.z = lmd->st.q.z;
+        nos_host::RightMultiplyNormalize(&q, nos_host::ExpQuat(step + 3));
+        lmd->st.q.w = q.w, lmd->st.q.x = q.x, lmd->st.q.y = q.y, lmd->st.q.z = q.z;
+        double R[9];
+        nos_host::QuatToMatrix(q, R);
+#pragma unroll
+        for (int r = 0; r < 9; ++r) lmd->st.R[r] = R[r];
+      } else {
+        lmd->st.t[0] += step[0];
+        lmd->st.t[1] += step[1];
+        double c, sn;
+        sincos(step[2], &sn, &c);
+        const double a = lmd->st.R[0], b = lmd->st.R[1], dd = lmd->st.R[2], e = lmd->st.R[3];
+        lmd->st.R[0] = a * c + b * sn;  // linear <- linear * Rot2(dtheta)   (Isometry2d::rotate)
+        lmd->st.R[1] = b * c - a * sn;
+        lmd->st.R[2] = dd * c + e * sn;
+        lmd->st.R[3] = e * c - dd * sn;
+      }
+      if (nos_host::Norm<N>(step) < settings.parameter_tolerance || nos_host::Norm<N>(g) < settings.gradient_tolerance) {
+        lmd->st.done = 1;
+      } else {
+        const double lambda = lmd->st.lambda, previous = lmd->st.previous_cost;
+        if (settings.float_schedule) {
+          lmd->st.lambda = nos_host::NextLambdaFloat(lambda, cost, previous);
+          lmd->st.previous_cost = double(float(cost));
+        } else {
+          lmd->st.lambda = nos_host::NextLambda(lambda, cost, previous);
+          lmd->st.previous_cost = cost;
+        }
+        const int it = lmd->st.iteration + 1;
+        lmd->st.iteration = it;
+        if (it >= settings.max_iterations) lmd->st.done = 1;
+      }
+    }
+  }
+  wave_sync_lds();
+}
+
+// LDS address of a __shared__ object (the generic pointer HIP hands out, narrowed back to its address space)
+template <typename T>
+__device__ __forceinline__ __attribute__((address_space(3))) T* lds_ptr(T* p) {
+  return (__attribute__((address_space(3))) T*)p;
+}
+
 #ifdef NOS_LM_TIMING
 #define NOS_LM_STAMP(slot) \
   if (entry_host != nullptr) __hip_atomic_store(entry_host + 50 + (slot), double(wall_clock64()), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
@@ -992,18 +1139,9 @@ __device__ __forceinline__ bool lm_prologue(const FusedFinal& fin, Params& P) {
 #define NOS_LM_STAMP(slot)
 #endif
 
-template <int NOUT>
-__device__ __forceinline__ void lm_advance(const double* tot, nos_host::LmState st, const nos_host::LmSettings settings,
-                                           LmDevice* lm, double* entry_host) {
-  NOS_LM_STAMP(2);
-  double out[NOUT];
-#pragma unroll
-  for (int k = 0; k < NOUT; ++k) out[k] = tot[k];
-  if constexpr (NOUT == 28)
-    nos_host::LmAdvance6(settings, out, &st);
-  else
-    nos_host::LmAdvance3(settings, out, &st);
-  NOS_LM_STAMP(3);
+// One lane: the state after a step → device memory for the next launch and, if `entry_host` is set, the pinned log entry
+// the host is waiting for.
+__device__ __forceinline__ void lm_publish(const nos_host::LmState& st, LmDevice* lm, double* entry_host) {
   lm->st = st;
   if (entry_host != nullptr) {
 #pragma unroll
@@ -1019,7 +1157,6 @@ __device__ __forceinline__ void lm_advance(const double* tot, nos_host::LmState 
     __hip_atomic_store(entry_host + kLogDone, double(st.done), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(entry_host + kLogOk, double(st.ok), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
-  NOS_LM_STAMP(4);
 }
 
 template <int NOUT, int BLOCK>
@@ -1080,11 +1217,16 @@ __device__ __forceinline__ void finish_in_last_block(const double* partials, con
   const int slice = threadIdx.x / kCols;
   // the loop state is requested now so that its latency hides behind the row sums
   const bool step_here = fin.lm != nullptr && fin.lm_step != 0;  // grid-uniform
-  nos_host::LmState st_pre;
-  nos_host::LmSettings settings_pre;
+  __shared__ double s_lmd_raw[(sizeof(LmDevice) + 7) / 8];       // the loop state while wave 0 advances it
+  __shared__ double s_work[kLmWorkDoubles];
+  LmDevice& s_lmd = *reinterpret_cast<LmDevice*>(s_lmd_raw);
+  constexpr int kLmdWords = int(sizeof(LmDevice) / sizeof(double));
+  static_assert(sizeof(LmDevice) % sizeof(double) == 0, "LmDevice must be a whole number of doubles");
+  double lmd_pre[kLmdWords];  // thread 0: loop state + settings, in flight while the rows are summed
   if (step_here && threadIdx.x == 0) {
-    st_pre = fin.lm->st;
-    settings_pre = fin.lm->settings;
+    const double* src = reinterpret_cast<const double*>(fin.lm);
+#pragma unroll
+    for (int k = 0; k < kLmdWords; ++k) lmd_pre[k] = src[k];
   }
   // Thread (slice, col) adds rows slice, slice + S, slice + 2S, … in that order.  Sixteen row loads are put in flight
   // before the first add: the loop is latency bound (each row comes from another XCD's L2 / memory).
@@ -1130,19 +1272,28 @@ __device__ __forceinline__ void finish_in_last_block(const double* partials, con
     if (step_here) s_tot[threadIdx.x] = tot;
   }
   if (step_here) {
-    __syncthreads();
     if (threadIdx.x == 0) {
+#pragma unroll
+      for (int k = 0; k < kLmdWords; ++k) s_lmd_raw[k] = lmd_pre[k];
       if (exchange_failed) {  // a peer never arrived: stop the loop here, the host reports the error
-        st_pre.ok = 0;
-        st_pre.done = 1;
-        fin.lm->st = st_pre;
+        s_lmd.st.ok = 0;
+        s_lmd.st.done = 1;
+        fin.lm->st = s_lmd.st;
         if (fin.out_host != nullptr) {
           __hip_atomic_store(fin.out_host + kLogDone, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           __hip_atomic_store(fin.out_host + kLogOk, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
-      } else {
-        lm_advance<NOUT>(s_tot, st_pre, settings_pre, fin.lm, fin.out_host);
       }
+    }
+    __syncthreads();
+    if (threadIdx.x < kWave && !exchange_failed) {  // wave 0, all lanes (exchange_failed is block-uniform)
+      double* entry_host = fin.out_host;
+      (void)entry_host;
+      NOS_LM_STAMP(2);
+      lm_step_wave<NOUT>(lds_ptr(static_cast<const double*>(s_tot)), lds_ptr(&s_lmd), lds_ptr(s_work));
+      NOS_LM_STAMP(3);
+      if (threadIdx.x == 0) lm_publish(s_lmd.st, fin.lm, fin.out_host);
+      NOS_LM_STAMP(4);
     }
   }
   if (threadIdx.x < kWave) {
@@ -1334,6 +1485,7 @@ __global__ __launch_bounds__(BLOCK) void solve_single_block_kernel(TiledLayout L
   __shared__ double s_lm_raw[(sizeof(LmDevice) + 7) / 8];  // raw storage: the struct has default member initialisers
   LmDevice& s_lm = *reinterpret_cast<LmDevice*>(s_lm_raw);
   __shared__ double s_sum[kOut];
+  __shared__ double s_work[kLmWorkDoubles];
   if (threadIdx.x == 0) s_lm = *lm;
   __syncthreads();
   int executed = 0;
@@ -1372,16 +1524,10 @@ __global__ __launch_bounds__(BLOCK) void solve_single_block_kernel(TiledLayout L
     for (int k = 0; k < kOut; ++k) dacc[k] = double(acc[k]);
     block_reduce_store<kOut, BLOCK>(dacc, s_sum, false);
     __syncthreads();
-    if (threadIdx.x == 0) {
-      double out[kOut];
-#pragma unroll
-      for (int k = 0; k < kOut; ++k) out[k] = s_sum[k];
-      if (cost_history != nullptr && executed < history_capacity)
-        __hip_atomic_store(cost_history + executed, out[kOut - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      if constexpr (kOut == 28)
-        nos_host::LmAdvance6(s_lm.settings, out, &s_lm.st);
-      else
-        nos_host::LmAdvance3(s_lm.settings, out, &s_lm.st);
+    if (threadIdx.x < kWave) {  // wave 0 advances the loop (nos_host::LmAdvance*, wave-parallel)
+      if (threadIdx.x == 0 && cost_history != nullptr && executed < history_capacity)
+        __hip_atomic_store(cost_history + executed, s_sum[kOut - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      lm_step_wave<kOut>(lds_ptr(static_cast<const double*>(s_sum)), lds_ptr(&s_lm), lds_ptr(s_work));
     }
     ++executed;
     __syncthreads();
@@ -1524,8 +1670,10 @@ __global__ __launch_bounds__(BLOCK) void solve_cluster_kernel(TiledLayout L, typ
   __shared__ double red[kSlices][kCols];
   __shared__ double s_tot[kOut];
   __shared__ double s_pose[12];
-  __shared__ double s_state_raw[(sizeof(nos_host::LmState) + 7) / 8];  // this workgroup's copy of the loop state
-  nos_host::LmState& s_state = *reinterpret_cast<nos_host::LmState*>(s_state_raw);
+  __shared__ double s_lmd_raw[(sizeof(LmDevice) + 7) / 8];  // this workgroup's copy of the loop state and settings
+  __shared__ double s_work[kLmWorkDoubles];
+  LmDevice& s_lmd = *reinterpret_cast<LmDevice*>(s_lmd_raw);
+  nos_host::LmState& s_state = s_lmd.st;
 
   // This workgroup's correspondences, read ONCE: slot j of lane l is item  block_base + j * BLOCK + l  (a wave reads
   // consecutive items of one field per load).  Slots beyond n are zero records (contribute exactly nothing) and are
@@ -1581,8 +1729,8 @@ __global__ __launch_bounds__(BLOCK) void solve_cluster_kernel(TiledLayout L, typ
       for (int f = 0; f < kF; ++f) resident[(size_t(j - RI) * kF + f) * BLOCK + threadIdx.x] = xi[f];
     }
   }
-  const nos_host::LmSettings settings = lm->settings;  // constant during the launch
   if (threadIdx.x == 0) {
+    s_lmd.settings = lm->settings;  // constant during the launch
     s_state = lm->st;  // written by lm_init_kernel before this launch
     s_flag = s_state.done != 0 ? 1 : 0;
     s_fast = 0;
@@ -1846,23 +1994,13 @@ __global__ __launch_bounds__(BLOCK) void solve_cluster_kernel(TiledLayout L, typ
     }  // PROTO
     {
       NOS_RES_STAMP(3)  // rows → sums
-      if (threadIdx.x == 0) {
-        double out[kOut];
-#pragma unroll
-        for (int k = 0; k < kOut; ++k) out[k] = s_tot[k];
-        if (blockIdx.x == 0 && cost_history != nullptr && executed < history_capacity)
-          __hip_atomic_store(cost_history + executed, out[kOut - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        nos_host::LmState st = s_state;
-        if constexpr (kOut == 28)
-          nos_host::LmAdvance6(settings, out, &st);
-        else
-          nos_host::LmAdvance3(settings, out, &st);
-        s_state = st;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) s_pose[k] = st.R[k];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) s_pose[9 + k] = st.t[k];
-        s_flag = st.done != 0 ? 1 : 0;
+      if (threadIdx.x < kWave) {  // wave 0 of EVERY workgroup advances its own copy of the loop (identical bits everywhere)
+        if (threadIdx.x == 0 && blockIdx.x == 0 && cost_history != nullptr && executed < history_capacity)
+          __hip_atomic_store(cost_history + executed, s_tot[kOut - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        lm_step_wave<kOut>(lds_ptr(static_cast<const double*>(s_tot)), lds_ptr(&s_lmd), lds_ptr(s_work));
+        if (threadIdx.x < 9) s_pose[threadIdx.x] = s_state.R[threadIdx.x];
+        if (threadIdx.x < 3) s_pose[9 + threadIdx.x] = s_state.t[threadIdx.x];
+        if (threadIdx.x == 0) s_flag = s_state.done != 0 ? 1 : 0;
       }
     }
     ++executed;
@@ -2100,6 +2238,9 @@ template <int NOUT>
 __global__ __launch_bounds__(64) void lm_step_kernel(const double* __restrict__ sums, LmDevice* lm, double* entry_host,
                                                      unsigned long long* seq_host, unsigned long long seq) {
   __shared__ double s_tot[NOUT];
+  __shared__ double s_lmd_raw[(sizeof(LmDevice) + 7) / 8];
+  __shared__ double s_work[kLmWorkDoubles];
+  LmDevice& s_lmd = *reinterpret_cast<LmDevice*>(s_lmd_raw);
   const int done = *reinterpret_cast<const volatile int*>(&lm->st.done);  // loop finished earlier: forward seq only
   if (done == 0) {
     if (threadIdx.x < NOUT) {
@@ -2108,8 +2249,13 @@ __global__ __launch_bounds__(64) void lm_step_kernel(const double* __restrict__ 
       if (entry_host != nullptr)
         __hip_atomic_store(entry_host + kLogOut + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    if (threadIdx.x == 0) {
+      s_lmd.st = lm->st;
+      s_lmd.settings = lm->settings;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) lm_advance<NOUT>(s_tot, lm->st, lm->settings, lm, entry_host);
+    lm_step_wave<NOUT>(lds_ptr(static_cast<const double*>(s_tot)), lds_ptr(&s_lmd), lds_ptr(s_work));  // one wave
+    if (threadIdx.x == 0) lm_publish(s_lmd.st, lm, entry_host);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (threadIdx.x == 0 && seq_host != nullptr) {

@@ -199,7 +199,7 @@ bool MahalanobisDistanceMinimizerHip::Prepare(const std::vector<Correspondence>&
   }
   size_t offsets[NOS_NDT_PLANES];
   NdtFieldOffsets(offsets);
-  const size_t count = hip_options_.simd_class ? SimdClassCount(correspondences.size(), hip_options_.simd_class_threads)
+  const size_t count = hip_options_.simd_class ? SimdClassCount(correspondences.size(), SimdClassThreads())
                                                : correspondences.size();
   int rc = nos_ndt_dataset_create_from_records(runtime_->ctx(), count, correspondences.data(), sizeof(Correspondence),
                                                offsets, hip_options_.dtype, &prepared_);

@@ -106,6 +106,10 @@ class MahalanobisDistanceMinimizerHip : public MahalanobisDistanceMinimizer {
 
  protected:
   virtual bool RunLoop(const Options& options, nos_dataset* dataset, const nos_loss& loss, Pose* pose);
+  // T of the SIMD class's tail drop T * floor(floor(N/8)/T) * 8: the 6-DoF class splits over its executor's threads
+  // (MDM/..._analytic_simd.cc:46-69); the 3-DoF SIMD class has no executor and always uses floor(N/8)*8
+  // (MDM/..._analytic_3dof_simd.cc:83-86).
+  virtual int SimdClassThreads() const { return hip_options_.simd_class_threads; }
   HipOptions hip_options_;
   std::shared_ptr<HipRuntime> runtime_;
   nos_dataset* prepared_{nullptr};
@@ -120,6 +124,7 @@ class MahalanobisDistanceMinimizerHip3DOF : public MahalanobisDistanceMinimizerH
 
  protected:
   bool RunLoop(const Options& options, nos_dataset* dataset, const nos_loss& loss, Pose* pose) final;
+  int SimdClassThreads() const final { return 1; }
 };
 
 }  // namespace mahalanobis_distance_minimizer

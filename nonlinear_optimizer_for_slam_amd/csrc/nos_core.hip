@@ -38,11 +38,8 @@ static std::string dir_of_symbol(const void* symbol, std::string* file_out = nul
 // runtime already mapped into the process (so runtime and collectives always come from one ROCm tree — a process that
 // imported torch first runs on torch's bundled runtime and gets torch's bundled librccl; one that did not gets the
 // system pair), then the loader's default search.
-RcclApi* Rccl() {
-  static RcclApi api;
-  static bool tried = false;
-  if (tried) return &api;
-  tried = true;
+namespace {
+void LoadRccl(RcclApi& api) {
   std::vector<std::string> names;
   if (const char* forced = getenv("NOS_RCCL_PATH")) names.push_back(forced);
   const std::string hip_dir = dir_of_symbol(reinterpret_cast<const void*>(&hipGetDeviceCount));
@@ -57,7 +54,7 @@ RcclApi* Rccl() {
     api.handle = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL);
     if (api.handle) break;
   }
-  if (!api.handle) return &api;
+  if (!api.handle) return;
   api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(api.handle, "ncclGetUniqueId"));
   api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(api.handle, "ncclCommInitRank"));
   api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.handle, "ncclCommDestroy"));
@@ -67,6 +64,14 @@ RcclApi* Rccl() {
   api.GetVersion = reinterpret_cast<decltype(api.GetVersion)>(dlsym(api.handle, "ncclGetVersion"));
   api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllReduce && api.GetErrorString;
   if (api.ok) dir_of_symbol(reinterpret_cast<const void*>(api.AllReduce), &api.path);
+}
+}  // namespace
+
+// Process-wide, bound once: two threads that each own a context may get here at the same time (std::call_once).
+RcclApi* Rccl() {
+  static RcclApi api;
+  static std::once_flag once;
+  std::call_once(once, [] { LoadRccl(api); });
   return &api;
 }
 
@@ -170,15 +175,21 @@ int launch_by_variant(int variant, int blocks_per_cu, int num_cus, const nos::Ti
     return launch_variant<Problem, T, ITEMS_, BLOCK_, MINW_, true>(L, P, bpc * num_cus, num_cus, nt, partials, fin, \
                                                                    stream, rows_out);               \
   }
+  // The default build carries the geometries something selects by default or a test drives (fp64 0, 1, 3; fp32 0, 1, 8);
+  // the others lost every measurement (profiles/r01_tune_*.txt, r02_tune_f32*.txt), several of them spill, and together
+  // they were two thirds of the 430 kernels of this translation unit.  `make ALL_VARIANTS=1` (-DNOS_ALL_VARIANTS) compiles
+  // them all again for tools/tune_*.py and the geometry test.
   if constexpr (sizeof(T) == 8) {
     switch (variant) {
       NOS_CASE(0, 1, 512, 3, 1)
       NOS_CASE(1, 1, 256, 3, 2)
-      NOS_CASE(2, 1, 256, 2, 2)
       NOS_CASE(3, 2, 256, 2, 2)
+#ifdef NOS_ALL_VARIANTS
+      NOS_CASE(2, 1, 256, 2, 2)
       NOS_CASE(4, 2, 512, 2, 1)
       NOS_CASE_PF(5, 1, 512, 2, 1)
       NOS_CASE_PF(6, 1, 256, 2, 2)
+#endif
     }
   } else {
     if (variant == 0 && L.tile_stride != 0) variant = 8;  // the default follows the layout (see kDefaultTileLog2F32)
@@ -189,20 +200,23 @@ int launch_by_variant(int variant, int blocks_per_cu, int num_cus, const nos::Ti
       // (0.1030 against 0.1011 ms per LM iteration), so the 16-byte-load form stays the default.
       NOS_CASE(0, 4, 256, 2, 1)      // default on planar planes: 16-byte loads, one wave per SIMD
       NOS_CASE(1, 2, 512, 2, 1)  // the fp64 default's shape: 8-byte loads, two waves per SIMD
+      NOS_CASE_PF(8, 2, 512, 2, 1)   // default on the tiled layout
+#ifdef NOS_ALL_VARIANTS
       NOS_CASE(2, 1, 256, 4, 2)
       NOS_CASE(3, 2, 256, 5, 2)
       NOS_CASE(4, 2, 256, 4, 2)
       NOS_CASE(5, 1, 1024, 4, 1)  // four waves per SIMD, 4-byte loads
       NOS_CASE(6, 2, 1024, 4, 1)  // four waves per SIMD, 8-byte loads
       NOS_CASE_PF(7, 4, 256, 2, 1)   // the default's shape, next chunk's loads in flight during the item math
-      NOS_CASE_PF(8, 2, 512, 2, 1)   // default on the tiled layout
       NOS_CASE(9, 2, 256, 3, 3)      // three waves per SIMD from three small workgroups per CU
       NOS_CASE_PF(10, 2, 256, 3, 3)
+#endif
     }
   }
 #undef NOS_CASE
 #undef NOS_CASE_PF
-  return fail(NOS_ERR_INVALID_ARGUMENT, "bad variant");
+  return fail(NOS_ERR_UNSUPPORTED, "launch geometry %d is not compiled into this build for this element type "
+              "(default build: fp64 0, 1, 3; fp32 0, 1, 8; `make ALL_VARIANTS=1` builds all)", variant);
 }
 
 // Correspondences a lane of the resident one-launch solve can hold (registers + LDS), by plane count and element type.
@@ -265,12 +279,13 @@ int launch_single(const nos::TiledLayout& L, const typename Problem::Params& P, 
                                         : nos::solve_cluster_kernel<Problem, T, kBlock, Shape::RI, Shape::LI, 1>;
     const size_t lds_items = a.items_per_lane > Shape::RI ? size_t(a.items_per_lane - Shape::RI) : 0;
     const size_t dyn_bytes = lds_items * size_t(Problem::kFields) * kBlock * sizeof(T);
-    static size_t lds_granted[2] = {0, 0};  // per instantiation and protocol: dynamic LDS beyond the default limit is requested once
-    if (dyn_bytes > lds_granted[a.protocol == 0 ? 0 : 1]) {
+    // Dynamic LDS beyond the default limit has to be granted per kernel AND per device (the attribute belongs to the
+    // function on the current device): asked for on every launch that needs it — a host-side call of about a microsecond,
+    // once per solve — instead of remembered in a process-wide static that a second device or thread would trip over.
+    if (dyn_bytes > size_t(48) * 1024) {
       const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(dyn_bytes));
       if (ea != hipSuccess) return fail(NOS_ERR_HIP, "resident solve: %zu bytes of LDS refused: %s", dyn_bytes, hipGetErrorString(ea));
-      lds_granted[a.protocol == 0 ? 0 : 1] = dyn_bytes;
     }
     hipLaunchKernelGGL(kernel, dim3(a.cluster_blocks), dim3(kBlock), dyn_bytes, stream, L, P, a.partials, a.lm, a.ctl,
                        a.history, a.history_capacity, a.entry, a.seq_host, a.seq,
@@ -734,8 +749,11 @@ int lm_solve(nos_dataset* ds, const Request& rq, const nos_lm_options* opt, doub
   const bool stream_form = !resident_fits && (ctx->settings.lm_cluster == 1 || ctx->settings.lm_cluster == 5) && items_per_lane >= 1 &&
                            sh.layout.n_padded % stream_chunk == 0 && sh.layout.n_padded / stream_chunk < (size_t(1) << 31) &&
                            (sh.layout.tile_stride == 0 || (size_t(sh.layout.tile_mask) + 1) % stream_chunk == 0);
+  if (slot.cluster_gave_up &&
+      std::chrono::steady_clock::now() - slot.cluster_gave_up_at > std::chrono::milliseconds(ctx->settings.lm_cluster_retry_ms))
+    slot.cluster_gave_up = false;  // try the one-launch form again
   if (ds->kind != kKindNdtIndexed && !with_comm && ctx->shm_dev == nullptr && opt->max_iterations > 0 &&
-      cluster_blocks >= 1 && (resident_fits || stream_form) &&
+      cluster_blocks >= 1 && (resident_fits || stream_form) && !slot.cluster_gave_up &&
       ctx->settings.lm_cluster != 0 && (opt->cost_history == nullptr || opt->max_iterations <= kHistCapacity)) {
     SingleBlockArgs cl{};
     cl.cluster_blocks = int(cluster_blocks);
@@ -763,12 +781,12 @@ int lm_solve(nos_dataset* ds, const Request& rq, const nos_lm_options* opt, doub
       NOS_HIP_CHECK(hipStreamSynchronize(slot.stream));
     }
     int rows = 0;
-    int rc = launch_assemble_raw(ds, sh, rq, slot.partials, nos::FusedFinal{}, slot.stream, &rows, &cl);
-    if (rc != NOS_OK) return rc;
+    // a launch that cannot be made (e.g. the LDS grant refused) is treated like one that gave up: the loop below runs instead
+    const bool launched_ok = launch_assemble_raw(ds, sh, rq, slot.partials, nos::FusedFinal{}, slot.stream, &rows, &cl) == NOS_OK;
     // spin on the sequence word; a launch that gave up never writes it
     volatile unsigned long long* seqw = reinterpret_cast<volatile unsigned long long*>(slot.h_out + kSeqSlot);
     bool finished = false;
-    for (long spins = 0; spins < 4000000; ++spins) {
+    for (long spins = 0; launched_ok && spins < 4000000; ++spins) {
       if (*seqw >= cl.seq) {
         finished = true;
         break;
@@ -814,7 +832,13 @@ int lm_solve(nos_dataset* ds, const Request& rq, const nos_lm_options* opt, doub
       }
       return NOS_OK;
     }
-    // gave up: put the shared words back in order and fall through to the launch-per-iteration loop from the start
+    // gave up: put the shared words back in order and fall through to the launch-per-iteration loop from the start.
+    // A real give-up (not the test hook) means the GPU is shared: remember it for a while, so the next solves on this
+    // device do not each pay the bounded wait before falling back ("lm_cluster_retry_ms").
+    if (ctx->settings.debug_cluster_abort == 0) {
+      slot.cluster_gave_up = true;
+      slot.cluster_gave_up_at = std::chrono::steady_clock::now();
+    }
     NOS_HIP_CHECK(hipMemsetAsync(slot.d_cluster, 0, sizeof(nos::ClusterCtl), slot.stream));
     hipLaunchKernelGGL(nos::lm_init_kernel, dim3(1), dim3(1), 0, slot.stream, slot.d_lm, init);
     NOS_HIP_CHECK(hipGetLastError());
@@ -1329,6 +1353,11 @@ using namespace nosd;
 
 extern "C" {
 
+namespace {
+// defined next to the option table: a knob read from the environment outside its range goes back to its default
+void drop_out_of_range_settings(nosd::Settings& st);
+}  // namespace
+
 int nos_ctx_create(const int* device_ids, int n_devices, nos_ctx** out_ctx) {
   if (!out_ctx) return fail(NOS_ERR_INVALID_ARGUMENT, "out_ctx is NULL");
   *out_ctx = nullptr;
@@ -1366,6 +1395,7 @@ int nos_ctx_create(const int* device_ids, int n_devices, nos_ctx** out_ctx) {
     st.pgo_host_scalars = env_int("NOS_PGO_HOST_SCALARS", st.pgo_host_scalars);
     st.pgo_precond = env_int("NOS_PGO_PRECOND", st.pgo_precond);
     st.pgo_agg = env_int("NOS_PGO_AGG", st.pgo_agg);
+    drop_out_of_range_settings(st);  // the same ranges nos_ctx_set_option enforces
   }
   for (int i = 0; i < n_devices; ++i) {
     DeviceSlot& s = ctx->slots[i];
@@ -1502,18 +1532,46 @@ namespace {
 struct OptionEntry {
   const char* key;
   int nosd::Settings::*field;
+  int lo, hi;
 };
 const OptionEntry kOptions[] = {
-    {"plane_skew", &nosd::Settings::plane_skew}, {"sc1", &nosd::Settings::sc1}, {"nt", &nosd::Settings::nt},
-    {"fused", &nosd::Settings::fused}, {"lm_fused", &nosd::Settings::lm_fused}, {"lm_window", &nosd::Settings::lm_window},
-    {"lm_single", &nosd::Settings::lm_single}, {"lm_cluster", &nosd::Settings::lm_cluster}, {"pool", &nosd::Settings::pool},
-    {"tile_log2", &nosd::Settings::tile_log2}, {"ingest", &nosd::Settings::ingest},
-    {"ingest_threads", &nosd::Settings::ingest_threads}, {"indexed_bpc", &nosd::Settings::indexed_bpc},
-    {"match_dense", &nosd::Settings::match_dense}, {"pgo_host_scalars", &nosd::Settings::pgo_host_scalars},
-    {"pgo_precond", &nosd::Settings::pgo_precond}, {"pgo_agg", &nosd::Settings::pgo_agg},
-    {"map_fma_mask", &nosd::Settings::map_fma_mask}, {"map_eigen_version", &nosd::Settings::map_eigen_version},
-    {"debug_cluster_abort", &nosd::Settings::debug_cluster_abort},
+    // key, field, lowest and highest accepted value
+    {"plane_skew", &nosd::Settings::plane_skew, 0, 1 << 20},
+    {"sc1", &nosd::Settings::sc1, 0, 1},
+    {"nt", &nosd::Settings::nt, -1, 1},
+    {"fused", &nosd::Settings::fused, 0, 1},
+    {"lm_fused", &nosd::Settings::lm_fused, 0, 1},
+    {"lm_window", &nosd::Settings::lm_window, 1, nosd::kLogSlots - 2},
+    {"lm_single", &nosd::Settings::lm_single, 0, 1},
+    {"lm_cluster", &nosd::Settings::lm_cluster, 0, 5},
+    {"lm_cluster_retry_ms", &nosd::Settings::lm_cluster_retry_ms, 0, 3600000},
+    {"pool", &nosd::Settings::pool, 0, 1},
+    {"tile_log2", &nosd::Settings::tile_log2, -1, 24},
+    {"ingest", &nosd::Settings::ingest, 0, 2},
+    {"ingest_threads", &nosd::Settings::ingest_threads, 0, 1024},
+    {"indexed_bpc", &nosd::Settings::indexed_bpc, 1, 16},
+    {"match_dense", &nosd::Settings::match_dense, 0, 1},
+    {"pgo_host_scalars", &nosd::Settings::pgo_host_scalars, 0, 1},
+    {"pgo_precond", &nosd::Settings::pgo_precond, 0, 1},
+    {"pgo_agg", &nosd::Settings::pgo_agg, 2, 1 << 20},
+    {"map_fma_mask", &nosd::Settings::map_fma_mask, 0, (1 << 26) - 1},
+    {"map_eigen_version", &nosd::Settings::map_eigen_version, 33, 34},
+    {"debug_cluster_abort", &nosd::Settings::debug_cluster_abort, 0, 1},
 };
+bool option_in_range(const OptionEntry& o, int value);
+void drop_out_of_range_settings(nosd::Settings& st) {
+  const nosd::Settings defaults;
+  for (const OptionEntry& o : kOptions)
+    if (!option_in_range(o, st.*(o.field))) {
+      fprintf(stderr, "[nos-hip] NOS_%s = %d is outside [%d, %d]: ignored\n", o.key, st.*(o.field), o.lo, o.hi);
+      st.*(o.field) = defaults.*(o.field);
+    }
+}
+bool option_in_range(const OptionEntry& o, int value) {
+  if (value < o.lo || value > o.hi) return false;
+  if (!strcmp(o.key, "tile_log2")) return value <= 0 || value >= 10;  // -1 by element type, 0 planar, tiles of 2^10 … 2^24
+  return true;
+}
 }  // namespace
 
 int nos_ctx_set_option(nos_ctx* ctx, const char* key, int value) {
@@ -1521,6 +1579,8 @@ int nos_ctx_set_option(nos_ctx* ctx, const char* key, int value) {
   nosd::CtxGuard guard_(ctx);
   for (const OptionEntry& o : kOptions)
     if (!strcmp(o.key, key)) {
+      if (!option_in_range(o, value))
+        return fail(NOS_ERR_INVALID_ARGUMENT, "option '%s' = %d is outside [%d, %d]", key, value, o.lo, o.hi);
       ctx->settings.*(o.field) = value;
       for (DeviceSlot& s : ctx->slots) s.pool_enabled = ctx->settings.pool != 0;
       return NOS_OK;
@@ -2045,7 +2105,11 @@ const char* nos_status_string(int status) {
 }
 
 const char* nos_last_error(void) { return nosd::last_error_text(); }
-const char* nos_version(void) { return "nos-hip 0.1 (gfx950)"; }
+#ifdef NOS_ALL_VARIANTS
+const char* nos_version(void) { return "nos-hip 0.3 (gfx950, all launch geometries)"; }
+#else
+const char* nos_version(void) { return "nos-hip 0.3 (gfx950)"; }
+#endif
 
 }  // extern "C"
 

@@ -113,6 +113,8 @@ struct DeviceSlot {
   std::vector<PoolEntry> pool;
   size_t pool_bytes = 0;
   bool pool_enabled = true;  // Settings::pool
+  bool cluster_gave_up = false;  // the last one-launch solve on this device timed out waiting for its grid (shared GPU)
+  std::chrono::steady_clock::time_point cluster_gave_up_at{};
   std::vector<hipEvent_t> prof_events;
   size_t prof_used = 0;
   bool prof_on = false;
@@ -135,6 +137,7 @@ struct Settings {
   int lm_fused = 1;          // NOS_LM_FUSED        LM step in the finishing workgroup
   int lm_window = 3;         // NOS_LM_WINDOW       launches kept in flight by the device loop
   int lm_single = 1;         // NOS_LM_SINGLE       whole solve in one workgroup for tiny problems
+  int lm_cluster_retry_ms = 5000;  // after a one-launch solve gave up (GPU shared): how long the context goes straight to the launch-per-iteration loop
   int lm_cluster = 1;        // NOS_LM_CLUSTER      whole solve in one launch (resident on chip, or streamed per iteration beyond that); 5 = all-reduce stage 1 always through sc1 stores, 4 = resident form only, 3 = counter protocol, 2 = one item per lane, 0 = off
   int pool = 1;              // NOS_POOL            device-buffer pool
   int tile_log2 = -1;        // NOS_TILE_LOG2       -1 = by element type (fp64 planar, fp32 1024-item tiles), 0 = planar

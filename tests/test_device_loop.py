@@ -275,7 +275,9 @@ def test_single_workgroup_reprojection_known_answer_and_planar(ctx, oracle):
     np.testing.assert_allclose(t2, want["t"][:2], atol=1e-9)
     R2f, t2f, repf = ds.solve3(np.eye(2), np.zeros(2), EXP, max_iterations=100)
     assert repf["launches"] == 1
-    np.testing.assert_allclose(t2f, want["t"][:2], atol=2e-5)  # 900 points in fp32: SURVEY §8(d)'s bound
+    # 900 points in fp32 storage: measured 1.56e-6 (gpurun_out/r02_gputests_b.log) — the rounding of the inputs to float
+    # on a small problem; 4e-6 = 2.5 x measured, like the other fp32 tolerances (SURVEY §8(d) allows 2e-5)
+    np.testing.assert_allclose(t2f, want["t"][:2], atol=4e-6)
     ds.close()
     ds64.close()
 

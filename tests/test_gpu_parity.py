@@ -162,7 +162,11 @@ def test_async_result_in_torch_tensor_matches_sync(ctx):
 def test_every_launch_geometry_and_layout_gives_the_same_sums(oracle):
     """Every compiled launch geometry on every dataset layout (planar planes, 1024- and 4096-item tiles; the fp32 default
     is the 1024-item tile, the fp64 default planar).  A geometry whose chunk does not divide the tile, or that is not
-    compiled for the element type, must be refused with an error — never run."""
+    compiled for the element type, must be refused with an error — never run.  The default build carries fp64 geometries
+    0, 1, 3 and fp32 0, 1, 8; a `make ALL_VARIANTS=1` build (tools/, nos_version() says so) all 7 + 11."""
+    from nonlinear_optimizer_for_slam_amd import _lib
+    all_variants = b"all launch geometries" in _lib.hip_lib().nos_version()
+    compiled = {"f64": set(range(7)) if all_variants else {0, 1, 3}, "f32": set(range(11)) if all_variants else {0, 1, 8}}
     planes = synth.ndt_planes(123_457, 4000)
     loss = ("exponential", 1.0, 1.0)
     want = oracle.ndt6_accumulate(planes, R_TEST, T_TEST, loss)
@@ -178,15 +182,17 @@ def test_every_launch_geometry_and_layout_gives_the_same_sums(oracle):
                     try:
                         got = ds.accumulate6(R_TEST, T_TEST, loss)
                     except RuntimeError:
-                        # fp64 has 7 geometries; the 2048-item chunk of fp32 geometry 6 does not fit a 1024-item tile
-                        assert (dtype == "f64" and variant >= 7) or (dtype == "f32" and variant == 6 and tile in (-1, 10))
+                        # not compiled for the element type, or the 2048-item chunk of fp32 geometry 6 on a 1024-item tile
+                        assert variant not in compiled[dtype] or (dtype == "f32" and variant == 6 and tile in (-1, 10))
                         refused += 1
                         continue
+                    # fp32 geometry 0 on a tiled layout is served by geometry 8 (the default follows the layout)
+                    assert variant in compiled[dtype]
                     helpers.assert_normal_equations_close(got, want, 6, rtol)
                     ran += 1
             ds.close()
     c.close()
-    assert ran >= 4 * 3 * (7 + 10) and refused > 0
+    assert ran >= 4 * 3 * (len(compiled["f64"]) + len(compiled["f32"]) - 1) and refused > 0
 
 
 # ---------------------------------------------------------------- Solve() through the C++ classes

@@ -1,0 +1,58 @@
+"""No kernel the solve / accumulate entry points can select spills or uses scratch memory (not gpu: read from the code
+objects hipcc cross-compiled into csrc/*.o).
+
+Round 2's one-launch kernels carried the whole single-lane LM step inlined and sat at 256 VGPRs with 4-23 spilled
+registers; the step is now a wave-parallel noinline function (nos::lm_step_wave, csrc/assemble_kernels.hpp) whose
+registers are its own.  This test keeps it that way for every instantiation of the default build: ndt6 / ndt3 /
+reprojection x fp64 / fp32 x {no loss, exponential, Huber}, launch-per-pass (assemble_kernel), single workgroup, resident
+and streamed one-launch forms (solve_cluster_kernel), the stand-alone step kernel — and for the other translation units.
+"""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "nonlinear_optimizer_for_slam_amd", "csrc")
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+@pytest.fixture(scope="module")
+def core():
+    import kernel_resources
+    obj = os.path.join(CSRC, "nos_core.o")
+    assert os.path.exists(obj), "build with python __graft_entry__.py"
+    return kernel_resources.kernel_resources(obj)
+
+
+def test_hot_path_kernels_have_no_spills_and_no_scratch(core):
+    hot = [k for k in core if any(s in k["name"] for s in ("assemble_kernel<", "solve_cluster_kernel<",
+                                                           "solve_single_block_kernel<", "lm_step_kernel<"))]
+    # 3 problems x 2 element types x 3 losses of each form at least
+    for form, least in (("assemble_kernel<", 18), ("solve_cluster_kernel<", 36), ("solve_single_block_kernel<", 18),
+                        ("lm_step_kernel<", 2)):
+        assert sum(form in k["name"] for k in hot) >= least, form
+    bad = [(k["name"][:160], k["spill"], k["scratch"]) for k in hot if k["spill"] != 0 or k["scratch"] != 0]
+    assert not bad, bad
+    # the one-launch kernels run two waves per SIMD (one 512-thread workgroup per CU): at most 256 registers, and the
+    # default streaming kernel of the headline below that ceiling (room for what the scheduler wants to keep in flight)
+    headline = [k for k in hot if "solve_cluster_kernel<nos::Ndt6Problem<double, 1>, double, 512, 0, 0, 1, 1, false, true>" in k["name"]]
+    assert len(headline) == 1 and headline[0]["vgpr"] <= 248, headline
+
+
+def test_default_build_is_not_bloated(core):
+    """Round 2 compiled 430 kernels into this translation unit, 83 of them spilling (losing launch geometries kept
+    compiled); the default build now carries the geometries that are selected somewhere."""
+    assert len(core) <= 260, len(core)
+    assert all(k["spill"] == 0 and k["scratch"] == 0 for k in core), [k["name"][:120] for k in core if k["spill"] or k["scratch"]]
+
+
+@pytest.mark.parametrize("obj", ["nos_match.o", "nos_mapbuild.o", "nos_mapexact.o", "nos_indexed.o", "nos_pgo.o"])
+def test_other_translation_units_report(obj):
+    import kernel_resources
+    ks = kernel_resources.kernel_resources(os.path.join(CSRC, obj))
+    assert ks
+    spilling = [k["name"][:100] for k in ks if k["spill"] > 0]
+    # known and off the hot path: the voxel-indexed two-slot kernels (three-stage software pipeline) and the set-up kernel
+    # of the pose-graph coarse level's block cyclic reduction (6x6 blocks in registers, once per LM iteration)
+    assert all("assemble_indexed_kernel" in n or "pgo_pcr_setup_kernel" in n for n in spilling), spilling

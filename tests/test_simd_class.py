@@ -136,3 +136,28 @@ def test_ndt_lambda_schedule_runs_in_float_under_simd_class(ctx):
     rep = ds.set_simd_class(True).solve6(R0, t0, EXP, max_iterations=5, gradient_tolerance=1e30)[2]
     assert rep["iterations"] == 0 and rep["printed_cost"] == float(np.finfo(np.float32).max)
     ds.close()
+
+
+@pytest.mark.parametrize("dof", [6, 3])
+def test_tail_drop_with_an_executor_follows_each_class(oracle, dof):
+    """N = 8 * 3 * 41 + 21: not a multiple of 8 T for T = 3.  The 6-DoF SIMD class splits over its executor's threads and
+    uses T * floor(floor(N/8)/T) * 8 correspondences (MDM/..._analytic_simd.cc:46-69); the 3-DoF SIMD class has no executor
+    and always uses floor(N/8)*8 (MDM/..._analytic_3dof_simd.cc:83-86), whatever thread count the caller configured.  One
+    LM iteration from the identity: the printed cost is the cost of exactly the correspondences the class keeps."""
+    T = 3
+    n = 8 * T * 41 + 21
+    planes = synth.ndt_planes(n, 50)
+    keep = {6: T * ((n // 8) // T) * 8, 3: (n // 8) * 8}[dof]
+    assert {6: 984, 3: 1000}[dof] == keep and keep < n
+    cls = solvers.MahalanobisDistanceMinimizerHip if dof == 6 else solvers.MahalanobisDistanceMinimizerHip3DOF
+    s = cls(dtype="f64", simd_class=True, simd_class_threads=T)
+    s.SetLossFunction(EXP)
+    pose = solvers.Pose()
+    assert s.Solve(solvers.Options(max_iterations=1, gradient_tolerance=0.0, parameter_tolerance=0.0), planes, pose)
+    acc = oracle.ndt6_accumulate if dof == 6 else oracle.ndt3_accumulate
+    R0 = np.eye(3) if dof == 6 else np.eye(2)
+    t0 = np.zeros(3) if dof == 6 else np.zeros(2)
+    want = acc(planes[:, :keep], R0, t0, EXP)[-1]
+    other = acc(planes[:, :{6: 1000, 3: 984}[dof]], R0, t0, EXP)[-1]
+    got = s.report.printed_cost  # previous_cost after the one iteration = its cost (kept as a float in these classes)
+    assert abs(got - want) <= 1e-6 * want and abs(got - other) > 1e-4 * want

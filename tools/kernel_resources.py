@@ -9,20 +9,32 @@ import sys
 import tempfile
 
 LLVM = "/opt/rocm/lib/llvm/bin"
-obj = sys.argv[1]
-flt = sys.argv[2] if len(sys.argv) > 2 else ""
-with tempfile.TemporaryDirectory() as d:
-    fat, co = os.path.join(d, "fatbin"), os.path.join(d, "co")
-    subprocess.check_call([LLVM + "/llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, obj])
-    subprocess.check_call([LLVM + "/clang-offload-bundler", "--type=o", "--input=" + fat,
-                           "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co, "--unbundle"])
-    txt = subprocess.run([LLVM + "/llvm-readelf", "--notes", co], capture_output=True, text=True).stdout
-for b in re.split(r"\n\s+- \.agpr_count:", txt)[1:]:
-    name = re.search(r"\.name:\s+(\S+)", b).group(1)
-    if flt not in name:
-        continue
-    dem = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()
-    g = lambda k: int(re.search(r"\.%s:\s+(\d+)" % k, b).group(1))  # noqa: E731
-    print("agpr %3d vgpr %3d spill %3d scratch %5d lds %6d sgpr %3d  %s" % (
-        int(re.match(r"\s*(\d+)", b).group(1)), g("vgpr_count"), g("vgpr_spill_count"), g("private_segment_fixed_size"),
-        g("group_segment_fixed_size"), g("sgpr_count"), dem[:150]))
+
+
+def kernel_resources(obj):
+    """→ list of dicts {name (demangled), agpr, vgpr, spill, scratch, lds, sgpr} for every gfx950 kernel in `obj`
+    (an object file, shared library or executable with a .hip_fatbin section)."""
+    with tempfile.TemporaryDirectory() as d:
+        fat, co = os.path.join(d, "fatbin"), os.path.join(d, "co")
+        subprocess.check_call([LLVM + "/llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, obj])
+        subprocess.check_call([LLVM + "/clang-offload-bundler", "--type=o", "--input=" + fat,
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co, "--unbundle"])
+        txt = subprocess.run([LLVM + "/llvm-readelf", "--notes", co], capture_output=True, text=True).stdout
+    blocks = re.split(r"\n\s+- \.agpr_count:", txt)[1:]
+    names = [re.search(r"\.name:\s+(\S+)", b).group(1) for b in blocks]
+    dem = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.split("\n")
+    out = []
+    for b, name, d in zip(blocks, names, dem):
+        g = lambda k: int(re.search(r"\.%s:\s+(\d+)" % k, b).group(1))  # noqa: E731
+        out.append({"name": d.strip() or name, "agpr": int(re.match(r"\s*(\d+)", b).group(1)), "vgpr": g("vgpr_count"),
+                    "spill": g("vgpr_spill_count"), "scratch": g("private_segment_fixed_size"),
+                    "lds": g("group_segment_fixed_size"), "sgpr": g("sgpr_count")})
+    return out
+
+
+if __name__ == "__main__":
+    flt = sys.argv[2] if len(sys.argv) > 2 else ""
+    for k in kernel_resources(sys.argv[1]):
+        if flt in k["name"]:
+            print("agpr %3d vgpr %3d spill %3d scratch %5d lds %6d sgpr %3d  %s" % (
+                k["agpr"], k["vgpr"], k["spill"], k["scratch"], k["lds"], k["sgpr"], k["name"][:150]))
