@@ -64,6 +64,8 @@ def parse_args():
                     help="skip the 80 M-correspondence single-GPU pass (denominator of the 8-GPU strong-scaling claim)")
     ap.add_argument("--strong-points", type=int, default=80_000_000)
     ap.add_argument("--no-cold", action="store_true", help="skip the cold (evicted) / warm single-launch measurement")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short trains of the other single-GPU configurations (other_configs in the JSON line)")
     return ap.parse_args()
 
 
@@ -145,6 +147,10 @@ class Ndt6(Workload):
     def pose_error(self, t=None, R=None):
         return float(np.max(np.abs(np.asarray(self.pose_t if t is None else t) - self.pkg["synth"].true_pose("ndt")[1])))
 
+    def cpu_leg_fp64_avx(self, oracle):
+        R, t = np.eye(3), np.zeros(3)
+        return lambda p64, threads: oracle.avx_ndt6_accumulate_f64(p64, R, t, self.loss, threads=threads)
+
     def cpu_legs(self, oracle, planes):
         R, t = np.eye(3), np.zeros(3)
         return (lambda p32, threads: oracle.avx_ndt6_accumulate(p32, R, t, self.loss, threads=threads),
@@ -156,6 +162,7 @@ class Ndt6(Workload):
 class Ndt3(Ndt6):
     name, n_out = "ndt3", 10
     metric = "ndt3_gauss_newton_residual_blocks_per_sec"
+    cpu_leg_fp64_avx = None  # the reference has no fp64 AVX variant of the planar class
 
     def describe(self, n, world):
         return ("mahalanobis_distance_minimizer 3-DoF (planar) %s, %d points / %d NDT voxels per GPU — the data of "
@@ -305,12 +312,31 @@ def cpu_baseline(work, planes, seconds):
     except Exception:  # noqa: BLE001
         avx["cpu_model"] = "unknown"
     del p32
+    # the same-precision baseline of an fp64 GPU line: SolveDouble's 4-lane fp64 loop (6-DoF NDT only)
+    avx64 = None
+    fp64_fn = work.cpu_leg_fp64_avx(oracle) if getattr(work, "cpu_leg_fp64_avx", None) is not None else None
+    if fp64_fn is not None:
+        fp64_fn(planes[:, :80_000], cores)
+        tried = {}
+        for threads, share in ((cores, 0.6), (32, 0.3), (1, 0.3)):
+            if threads in tried or threads > cores:
+                continue
+            pk, ek = timed(lambda: fp64_fn(planes, threads), share * seconds)
+            tried[threads] = n * pk / ek
+        best_threads = max(tried, key=tried.get)
+        avx64 = {"value": tried[best_threads], "unit": "corr/s", "cores": best_threads, "kind": "port",
+                 "by_threads": {str(k): v for k, v in sorted(tried.items())},
+                 "sample": "full passes over the same %d-correspondence workload, AVX2+FMA 4-lane fp64 (restates the inner loop "
+                           "of SolveDouble, MDM/..._analytic_simd_various.cc:42-134, on planar planes — the reference gathers "
+                           "its 304-byte records every iteration and runs it on ONE thread; the thread fan-out here is the 6-DoF "
+                           "SIMD class's partition on multiples of 4); value = the fastest thread count tried (%d of %d visible "
+                           "cores)" % (n, best_threads, avail)}
     ns = min(n, 4_000_000)
     sub = np.ascontiguousarray(planes[:, :ns])
     passes, el = timed(lambda: scalar_fn(sub), seconds)
     scalar = {"value": ns * passes / el, "unit": "corr/s", "cores": 1, "kind": "port",
               "sample": "%d passes over the first %d correspondences, scalar fp64 (%s)" % (passes, ns, scalar_cite)}
-    return avx, scalar
+    return avx, scalar, avx64
 
 
 class _StdoutToStderr:
@@ -348,6 +374,29 @@ def check_runtime(api, need_rccl):
         print(msg, file=sys.stderr)
     info["skew"] = bool(problems)
     return info
+
+
+def dist_free_default(args):
+    """True for the default headline run (ndt6 fp64 flat, configs[1] size, device loop): the run that also carries short
+    trains of the other single-GPU configurations."""
+    return (args.problem == "ndt6" and args.dtype == "f64" and args.layout == "flat" and args.loop == "device"
+            and args.points in (0, 10_000_000) and not args.no_other_configs
+            and os.environ.get("NOS_BENCH_FORCE_DIST", "0") != "1")
+
+
+def valu_floor_ms(problem, dtype, n):
+    """VALU-issue floor of one pass: VALU instructions per correspondence from the newest committed SQ counter pass of the
+    streaming kernel of this problem (SQ_INSTS_VALU), 4 cycles per wave instruction, 1024 SIMDs, 2.4 GHz."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_*summary*.json")), reverse=True):
+        try:
+            prof = json.load(open(path))
+        except Exception:  # noqa: BLE001
+            continue
+        ipc = (prof.get("sq_derived") or {}).get("valu_instructions_per_correspondence")
+        if ipc and prof.get("dtype") == dtype and prof.get("problem", "ndt6") == problem and "solve_cluster" not in prof.get("kernel", ""):
+            return ipc * n / 64.0 * 4.0 / (1024.0 * 2.4e9) * 1e3, ipc, os.path.relpath(path, ROOT)
+    return None, None, None
 
 
 def summarize(values):
@@ -396,7 +445,8 @@ def main():
     n_local = args.points if args.points > 0 else work.default_points
     planes = work.planes(n_local, rank)
     ds = work.dataset(ctx, planes)
-    keep_planes = rank == 0 and world == 1 and not args.no_cpu_baseline
+    other_wanted = (world == 1 and dist_free_default(args))
+    keep_planes = rank == 0 and world == 1 and (not args.no_cpu_baseline or other_wanted)
     if not keep_planes:
         del planes
         planes = None
@@ -413,33 +463,34 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item())
 
-    def run_trains(iterate, bracket):
+    def run_trains(iterate, bracket, work=work, steps=args.steps, warmup=args.warmup, repeats=args.repeats,
+                   prewarm_target_ms=args.prewarm_ms):
         """prewarm → warm-up → R trains of K steps.  → dict(ms_per_step stats, kernel ms stats, launches)."""
         t_pre = time.perf_counter()
         iterate(50)
         fence()
         est = max_over_ranks(time.perf_counter() - t_pre)  # identical on every rank: the exchange inside is collective,
-        rounds = int(min(400, max(0, args.prewarm_ms * 1e-3 / max(est, 1e-6) - 1)))  # so the COUNT must be agreed on
+        rounds = int(min(400, max(0, prewarm_target_ms * 1e-3 / max(est, 1e-6) - 1)))  # so the COUNT must be agreed on
         for _ in range(rounds):
             iterate(50)
         fence()
         prewarm_ms = 1e3 * (time.perf_counter() - t_pre)
         work.reset_pose()
-        if args.warmup > 0:
-            iterate(args.warmup)
+        if warmup > 0:
+            iterate(warmup)
         fence()
         ms, kms, launches = [], [], 0
-        for _ in range(max(1, args.repeats)):
+        for _ in range(max(1, repeats)):
             work.reset_pose()  # every train does the same work: K iterations from the initial pose
             fence()
             if os.environ.get("NOS_BENCH_NO_EVENTS", "0") != "1":
-                ctx.profile_begin(args.steps + 8, sample_every=0 if bracket else 4)
+                ctx.profile_begin(steps + 8, sample_every=0 if bracket else 4)
             t0 = time.perf_counter()
-            iterate(args.steps)
+            iterate(steps)
             fence()
             elapsed = max_over_ranks(time.perf_counter() - t0)
             n_timed, k_mean, _, _ = ctx.profile_end()
-            ms.append(1e3 * elapsed / args.steps)
+            ms.append(1e3 * elapsed / steps)
             if n_timed > 0:
                 kms.append(k_mean)
                 launches += n_timed
@@ -532,6 +583,7 @@ def main():
                         for k, v in legs.items() if k != "main"}
 
     main_leg = legs["main"]
+    launched_kernel = ctx.last_kernel()  # the instantiation the library chose for the timed trains, by its symbol
     ms_med = main_leg["ms_per_step"]["median"]
     n_total = n_local * world
     value = n_total / (ms_med * 1e-3)
@@ -585,6 +637,45 @@ def main():
             "warm_GBps": bytes_per_launch / (warm["median"] * 1e-3) / 1e9,
             "cold_GBps": bytes_per_launch / (cold["median"] * 1e-3) / 1e9,
         }
+
+    # ---- the other single-GPU configurations, short trains with the same bracket timing (driver-timed lines instead of
+    # builder-run ones): configs[2], the configs[0] shape on the GPU, the fp32 classes' storage, the planar solver
+    other_configs = None
+    if dist is None and other_wanted and planes is not None:
+        other_configs = {}
+        specs = [("reproj_f64_2M (BASELINE.json configs[2])", "reproj", "f64", 2_000_000),
+                 ("ndt6_f64_100k (BASELINE.json configs[0] shape on the GPU)", "ndt6", "f64", 100_000),
+                 ("ndt6_f32_10M (configs[1] data, fp32 storage = the reference's SIMD classes)", "ndt6", "f32", n_local),
+                 ("ndt3_f64_10M (configs[1] data through the planar solver)", "ndt3", "f64", n_local)]
+        for label, problem, dtype, points in specs:
+            a2 = argparse.Namespace(**vars(args))
+            a2.problem, a2.dtype, a2.points, a2.layout = problem, dtype, points, "flat"
+            w2 = WORKLOADS[problem](a2, pkg)
+            p2 = w2.planes(points, 0) if problem == "reproj" else (planes if points == n_local else np.ascontiguousarray(planes[:, :points]))
+            d2 = w2.dataset(ctx, p2)
+            k2 = 40 if points >= 1_000_000 else 200
+            leg = run_trains(lambda k, w2=w2, d2=d2: w2.iterate_device(d2, k), bracket=True, work=w2, steps=k2, warmup=10,
+                             repeats=3, prewarm_target_ms=60.0)
+            sym = ctx.last_kernel()
+            b2 = d2.stream_bytes
+            med = leg["ms_per_step"]["median"]
+            floor, ipc, src = valu_floor_ms(problem, dtype, points)
+            entry = {"ms_per_step": leg["ms_per_step"], "steps": k2, "trains": 3, "points": points, "dtype": dtype,
+                     "bytes_per_step": b2, "frac_hbm": b2 / (med * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                     "value": points / (med * 1e-3), "unit": "corr/s",
+                     "valu_floor_ms": floor, "valu_instructions_per_corr": ipc, "valu_source": src,
+                     "launches_per_train": getattr(w2, "launches_of_last_solve", None), "kernel": sym,
+                     "kernel_ms_bracket": leg["kernel_ms"], "final_translation_error_m": leg["final_translation_error_m"],
+                     "timing": "as the headline: trains of K steps bracketed by device synchronisation; median of 3"}
+            if not args.no_cpu_baseline:
+                avx2, scalar2, avx64_2 = cpu_baseline(w2, p2, 1.0)
+                entry["cpu_baseline"] = avx2
+                entry["cpu_baseline_scalar_fp64"] = scalar2
+                if avx64_2 is not None:
+                    entry["cpu_baseline_fp64_avx"] = avx64_2
+            other_configs[label] = entry
+            d2.close()
+            del p2
 
     # ---- the denominator of the strong-scaling claim: configs[3]'s 80 M correspondences on ONE GPU
     strong = None
@@ -668,9 +759,9 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-            "kernel": (work.kernel_name().replace("assemble_kernel", "solve_cluster_kernel") +
-                       " (whole LM loop in one launch; kernel_ms = launch duration / iterations)"
-                       if device_loop and getattr(work, "launches_of_last_solve", 0) == 1 else work.kernel_name()),
+            "kernel": launched_kernel,  # nos_ctx_last_kernel: the symbol rocprofv3 --kernel-trace lists for these launches
+            "kernel_note": ("whole LM loop in ONE launch; kernel_ms = launch duration / iterations"
+                            if device_loop and getattr(work, "launches_of_last_solve", 0) == 1 else "one launch per LM iteration"),
             "kernel_ms": kern, "kernel_ms_mean": k_med,
             "launches_timed": main_leg["launches_timed"], "algorithmic_bytes_per_launch": bytes_per_launch,
             "bytes_per_corr": bytes_per_launch / max(n_local, 1),
@@ -737,11 +828,21 @@ def main():
                                                       "ncclCommCount": leg.get("ncclCommCount")}
         result["scaling_note"] = ("weak scaling: every rank keeps %d correspondences; N > 1 numbers exist only where this "
                                   "line was produced on N GPUs" % n_local)
-    if keep_planes:
-        avx, scalar = cpu_baseline(work, planes, args.cpu_seconds)
+    if other_configs is not None:
+        result["other_configs"] = other_configs
+    if keep_planes and not args.no_cpu_baseline:
+        avx, scalar, avx64 = cpu_baseline(work, planes, args.cpu_seconds)
         result["cpu_baseline"] = avx
         result["cpu_baseline_scalar_fp64"] = scalar
         result["gpu_over_cpu_avx"] = value / avx["value"]
+        if avx64 is not None:
+            result["cpu_baseline_fp64_avx"] = avx64
+        # same-precision ratio: an fp64 GPU line against the fp64 AVX loop, an fp32 one against the fp32 lanes
+        same = avx64 if (args.dtype == "f64" and avx64 is not None) else avx
+        result["gpu_over_cpu"] = {"value": value / same["value"], "cpu_leg": "cpu_baseline_fp64_avx" if same is avx64 else "cpu_baseline",
+                                  "cpu_threads": same["cores"],
+                                  "note": "same precision on both sides; a GPU / CPU ratio says nothing about kernel quality, "
+                                          "the roofline fraction does"}
     if rank == 0:
         print(json.dumps(result), flush=True)
     if dist is not None:

@@ -458,6 +458,10 @@ int nos_ndt3_time_kernel(nos_dataset* ds, const double R2[4], const double t2[2]
 int nos_ctx_profile_begin(nos_ctx* ctx, int max_launches, int sample_every);
 int nos_ctx_profile_end(nos_ctx* ctx, int* n_launches, double* mean_ms, double* min_ms,
                         double* max_ms);
+/* Demangled symbol of the hot-path kernel launched last on `shard` of this context ("" if none yet): the template
+ * instantiation the library chose — problem, element type, loss, launch geometry or loop form — exactly as
+ * rocprofv3 --kernel-trace lists it. */
+int nos_ctx_last_kernel(const nos_ctx* ctx, int shard, char* buf, size_t capacity);
 const char* nos_status_string(int status);
 /* Thread-local description of the last failure in this thread ("" if none). */
 const char* nos_last_error(void);

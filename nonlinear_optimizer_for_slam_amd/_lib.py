@@ -39,7 +39,7 @@ C_ABI_SYMBOLS = (
     "nos_ndt6_accumulate_async", "nos_ndt3_accumulate_async", "nos_reproj_accumulate_async",
     "nos_ndt6_solve", "nos_ndt3_solve", "nos_reproj_solve",
     "nos_ctx_set_launch", "nos_ctx_set_option", "nos_ctx_get_option", "nos_runtime_info", "nos_ctx_comm_rccl_count",
-    "nos_ctx_profile_begin", "nos_ctx_profile_end", "nos_ndt6_time_kernel", "nos_reproj_time_kernel",
+    "nos_ctx_last_kernel", "nos_ctx_profile_begin", "nos_ctx_profile_end", "nos_ndt6_time_kernel", "nos_reproj_time_kernel",
     "nos_ndt3_time_kernel", "nos_status_string", "nos_last_error", "nos_version",
 )
 
@@ -107,6 +107,8 @@ def _declare(lib):
     lib.nos_ctx_comm_destroy.argtypes = [vp]
     lib.nos_ctx_comm_size.argtypes = [vp]
     lib.nos_ctx_comm_allreduce.argtypes = [vp, dp, i]
+    if hasattr(lib, "nos_ctx_last_kernel"):  # absent from older builds loaded through NOS_HIP_LIB (tools/ab_resident.sh)
+        lib.nos_ctx_last_kernel.argtypes = [vp, i, ctypes.c_char_p, sz]
     lib.nos_ctx_profile_begin.argtypes = [vp, i, i]
     lib.nos_ctx_profile_end.argtypes = [vp, ctypes.POINTER(i), dp, dp, dp]
     lib.nos_ndt_dataset_create.argtypes = [vp, sz, ctypes.POINTER(dp), i, c_void_pp]
@@ -135,9 +137,11 @@ def _declare(lib):
     lib.nos_map_stats_size.restype = sz
     lib.nos_map_stats_get.argtypes = [vp, dp, dp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint32),
                                       ctypes.POINTER(ctypes.c_int64)]
-    lib.nos_map_stats_get_eigen.argtypes = [vp, dp, dp]
+    if hasattr(lib, "nos_map_stats_get_eigen"):
+        lib.nos_map_stats_get_eigen.argtypes = [vp, dp, dp]
     lib.nos_map_stats_destroy.argtypes = [vp]
-    lib.nos_dataset_drop_last_matches.argtypes = [vp, sz]
+    if hasattr(lib, "nos_dataset_drop_last_matches"):
+        lib.nos_dataset_drop_last_matches.argtypes = [vp, sz]
     ip = ctypes.POINTER(ctypes.c_int32)
     lib.nos_pgo_create.argtypes = [vp, sz, dp, sz, ip, ip, dp, dp, ctypes.c_char_p, ctypes.c_char_p, c_void_pp]
     lib.nos_pgo_destroy.argtypes = [vp]

@@ -171,6 +171,12 @@ class Context:
         check(self._lib.nos_ctx_comm_allreduce(self._h, _dp(v), v.size), "nos_ctx_comm_allreduce")
         return v
 
+    def last_kernel(self, shard=0):
+        """Demangled symbol of the hot-path kernel launched last on this context (nos_ctx_last_kernel)."""
+        buf = ctypes.create_string_buffer(1024)
+        check(self._lib.nos_ctx_last_kernel(self._h, shard, buf, len(buf)), "nos_ctx_last_kernel")
+        return buf.value.decode()
+
     def profile_begin(self, max_launches=4096, sample_every=1):
         check(self._lib.nos_ctx_profile_begin(self._h, max_launches, sample_every), "nos_ctx_profile_begin")
 

@@ -989,22 +989,23 @@ __device__ __forceinline__ bool lm_prologue(const FusedFinal& fin, Params& P) {
   return false;
 }
 
-// ---------------------------------------------------------------- the loop body on the device: one wave, data in LDS
+// ---------------------------------------------------------------- the loop body on the device: one lane, two real functions
 //
 // nos_host::LmAdvance6 / LmAdvance3 (csrc/host/nos_lm.hpp; the reference's loop body, MDM/..._analytic_simd.cc:78-102) as
-// ONE WAVE executes it in every device form of the loop (launch per iteration, stand-alone step kernel, single workgroup,
-// one-launch resident / streamed).  Round 2 ran that function inlined on one lane; unrolled for ILP it wanted ≈ 230
-// VGPRs (a 6x6 system, its factor, the sums, the state), which pinned every kernel that contained it at the 256-register
-// ceiling and made the streaming kernels spill around it.  Here the damped normal equations live in LDS, ONE element per
-// lane — lane (i, k) of a 6 x 7 arrangement owns a_ik (k <= i) or the right-hand side (k = 6) — and the right-looking LDLᵀ
-// with reciprocal pivots, the forward and the backward substitution of nos_host::SolveLdlt run across the lanes: the same
-// operations on every element in the same order (every update an explicit fma), so the result is that function's to the
-// bit wherever the compiler contracted it the same way.  Lane 0 then does the O(1) rest (pose update, tests, λ) with the
-// very functions the host loop uses.  A real (noinline) function: ≈ 40 VGPRs, none of them the streaming loop's.
-// All lanes of the calling wave must be active; `lmd`, `tot`, `work` are LDS; contains wave-level synchronisation only.
+// every device form of the loop runs it (launch per iteration, stand-alone step kernel, single workgroup, one-launch
+// resident / streamed).  Round 2 had that function inlined into the kernels; unrolled for instruction-level parallelism it
+// wanted ≈ 230 VGPRs (a 6x6 system, its factor, the sums, the state), which pinned every kernel that contained it at the
+// 256-register ceiling and made the streaming kernels spill around it.  Now it is two NOINLINE functions called by lane 0,
+// handing over through LDS — the damped solve (nos_host::DampedStep itself, ≈ 120 VGPRs) and the O(1) rest (pose update,
+// convergence tests, λ schedule) — so a kernel's own allocation is set by its hot loop and what it keeps alive across the
+// call (the streaming kernels: the prefetched first chunk of the next iteration).  A wave-parallel elimination (one matrix
+// element per lane, pivots by v_readlane, operands by ds_bpermute) was built and measured first: it needs only ≈ 40
+// registers but turns the step into ONE dependent chain — 2.45 µs against the 1.5 µs of the single lane's interleaved
+// chains (profiles/r03_lm_step_forms.txt) — so the single lane stayed.
+// `tot` is LDS: [0, NOUT) the sums, [NOUT, NOUT + N) receives the step, [NOUT + 7] 1.0 if the solve succeeded.
 using LdsDouble = __attribute__((address_space(3))) double;
 using LdsLmDevice = __attribute__((address_space(3))) LmDevice;
-constexpr int kLmWorkDoubles = 6 * 8;
+constexpr int kLmTotDoubles(int n_out) { return n_out + 8; }
 
 __device__ __forceinline__ void wave_sync_lds() {
   // LDS instructions of one wave execute in issue order; this only keeps the compiler from moving accesses across
@@ -1013,117 +1014,152 @@ __device__ __forceinline__ void wave_sync_lds() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+#ifdef NOS_LM_TIMING
+__shared__ unsigned long long s_step_cycles[4];  // probe build: shader-clock cycles of the two halves of the step
+#define NOS_STEP_TICK(slot_)                     \
+  {                                              \
+    const unsigned long long now_ = clock64();  \
+    s_step_cycles[slot_] += now_ - tick_;        \
+    tick_ = now_;                                \
+  }
+#else
+#define NOS_STEP_TICK(slot_)
+#endif
+
+// cos(x) and sin(x) / x as power series in v = x^2, for v < 1/256 (|x| < 1/16): six terms each, first omitted term < 1e-23
+__device__ __forceinline__ void series_cos_sinc(double v, double* c_out, double* sinc_out) {
+  double c = -1.0 / 3628800.0, sc = -1.0 / 39916800.0;
+  c = __builtin_fma(c, v, 1.0 / 40320.0), sc = __builtin_fma(sc, v, 1.0 / 362880.0);
+  c = __builtin_fma(c, v, -1.0 / 720.0), sc = __builtin_fma(sc, v, -1.0 / 5040.0);
+  c = __builtin_fma(c, v, 1.0 / 24.0), sc = __builtin_fma(sc, v, 1.0 / 120.0);
+  c = __builtin_fma(c, v, -0.5), sc = __builtin_fma(sc, v, -1.0 / 6.0);
+  *c_out = __builtin_fma(c, v, 1.0);
+  *sinc_out = __builtin_fma(sc, v, 1.0);
+}
+
+// First half: δ = -(H with its diagonal scaled by 1 + λ)^-1 g — nos_host::DampedStep, the host loop's own function
+// (right-looking LDLT with reciprocal pivots; on the device the reciprocal is the hardware seed + two Newton steps).
 template <int NOUT>
-__device__ __attribute__((noinline)) void lm_step_wave(const LdsDouble* tot, LdsLmDevice* lmd, LdsDouble* work) {
+__device__ __attribute__((noinline)) void lm_solve_lane(LdsDouble* tot, double lambda) {
   constexpr int N = NOUT == 28 ? 6 : 3;
-  constexpr int W = 8;  // row pitch of the work matrix: columns 0..N-1 lower triangle, column N right-hand side
-  const int lane = threadIdx.x & (kWave - 1);
-  const int i = lane / (N + 1), k = lane % (N + 1);
-  const bool in_sys = lane < N * (N + 1);
-  const bool lower = in_sys && k <= i;  // (k < N follows)
-  const bool rhs = in_sys && k == N;
-  double val = 0.0;
-  if (lower) {
-    val = tot[k * N - (k * (k - 1)) / 2 + (i - k)];  // H(k, i) of the upper triangle, row-major
-    if (i == k) val *= 1.0 + lmd->st.lambda;         // H_kk *= 1 + lambda
-  }
-  if (rhs) val = -tot[N * (N + 1) / 2 + i];
-  if (lower || rhs) work[i * W + k] = val;
-  wave_sync_lds();
-  bool ok = true;
-  double inv_i = 0.0, l_col = 0.0;
+#ifdef NOS_LM_TIMING
+  unsigned long long tick_ = clock64();
+#endif
+  double out[NOUT - 1], step[N];
 #pragma unroll
-  for (int j = 0; j < N; ++j) {
-    const double d = work[j * W + j];                 // the same word in every lane
-    if (!(d > 0.0) || !(d <= DBL_MAX)) {              // wave-uniform
-      ok = false;
-      break;
-    }
-    const double inv = 1.0 / d;
-    if (rhs && i == j) inv_i = inv;
-    if (in_sys && i > j) {
-      const double l = work[i * W + j] * inv;         // l_i = a_ij / d_j
-      if (k == j) l_col = l;                          // this lane's entry of L, stored after the loop
-      if (k > j && (k <= i || rhs)) {                 // a_ik -= l_i a_kj (j < k <= i);  y_i -= l_i y_j (k = N)
-        const double other = rhs ? work[j * W + N] : work[k * W + j];
-        val = __builtin_fma(-l, other, val);
-        work[i * W + k] = val;                        // never a word this step reads (column j, y_j)
-      }
-    }
-    wave_sync_lds();
-  }
-  if (ok) {
-    if (in_sys && k < i) work[i * W + k] = l_col;     // L below the diagonal
-    if (rhs) {
-      val *= inv_i;                                    // x = D^-1 y
-      work[i * W + N] = val;
-    }
-    wave_sync_lds();
+  for (int k = 0; k < NOUT - 1; ++k) out[k] = tot[k];
+  const bool solved = nos_host::DampedStep<N>(out, lambda, step);
 #pragma unroll
-    for (int c = N - 1; c > 0; --c) {                  // x_i -= L_ci x_c  (i < c)
-      if (rhs && i < c) {
-        val = __builtin_fma(-work[c * W + i], work[c * W + N], val);
-        work[i * W + N] = val;
-      }
-      wave_sync_lds();
-    }
+  for (int r = 0; r < N; ++r) tot[NOUT + r] = step[r];
+  tot[NOUT + 7] = solved ? 1.0 : 0.0;
+  NOS_STEP_TICK(0)
+}
+
+// Second half: pose update, the two convergence tests (after the update, as in the reference), λ schedule — the rest of
+// nos_host::LmAdvance6 / LmAdvance3 with the transcendental part written for a lone GPU lane, where every fp64 instruction
+// costs 8 cycles whatever it computes: the exponential map's two factors are even in θ and are summed as power series for
+// θ < 1/8 (no square root, no argument reduction, no division; sincos beyond), normalisation by reciprocal square root (seed
+// + two Newton steps), the tests on squared norms.  Within an ulp or two of the host loop's libm calls per operation.
+template <int NOUT>
+__device__ __attribute__((noinline)) void lm_finish_lane(const LdsDouble* tot, LdsLmDevice* lmd) {
+  constexpr int N = NOUT == 28 ? 6 : 3;
+#ifdef NOS_LM_TIMING
+  unsigned long long tick_ = clock64();
+#endif
+  const double lambda = lmd->st.lambda, previous_cost = lmd->st.previous_cost, cost = tot[NOUT - 1];
+  const int iteration = lmd->st.iteration;
+  const int max_iterations = lmd->settings.max_iterations, float_schedule = lmd->settings.float_schedule;
+  const double gtol = lmd->settings.gradient_tolerance, ptol = lmd->settings.parameter_tolerance;
+  const bool solved = tot[NOUT + 7] != 0.0;
+  double step[N], g2 = 0.0, s2 = 0.0;
+#pragma unroll
+  for (int r = 0; r < N; ++r) {
+    step[r] = tot[NOUT + r];
+    const double gr = tot[N * (N + 1) / 2 + r];
+    g2 = __builtin_fma(gr, gr, g2);
+    s2 = __builtin_fma(step[r], step[r], s2);
   }
-  if (lane == 0) {
-    const nos_host::LmSettings settings = {lmd->settings.max_iterations, lmd->settings.gradient_tolerance,
-                                           lmd->settings.parameter_tolerance, lmd->settings.float_schedule};
-    const double cost = tot[NOUT - 1];
-    lmd->st.cost = cost;
-    if (!ok) {
-      lmd->st.ok = 0;
-      lmd->st.done = 1;
+  lmd->st.cost = cost;
+  if (!solved) {
+    lmd->st.ok = 0;
+    lmd->st.done = 1;
+    NOS_STEP_TICK(1)
+    return;
+  }
+  if constexpr (N == 6) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) lmd->st.t[r] += step[r];
+    // ExpQuat (MahalanobisDistanceMinimizer::ComputeQuaternion, MDM/mahalanobis_distance_minimizer.cc:20-33):
+    //   theta < 1e-6: (1, w / 2);  else (cos(theta / 2), sin(theta / 2) / theta * w)
+    const double wx = step[3], wy = step[4], wz = step[5];
+    const double th2 = __builtin_fma(wx, wx, __builtin_fma(wy, wy, wz * wz));
+    double dw, kk;
+    if (th2 < 1.0 / 64.0) {
+      double c, sc;
+      series_cos_sinc(0.25 * th2, &c, &sc);
+      const bool tiny = !(th2 >= 1e-12);  // theta < 1e-6: the reference's un-normalised small-angle form
+      dw = tiny ? 1.0 : c;
+      kk = tiny ? 0.5 : 0.5 * sc;
     } else {
-      double step[N], g[N];
-#pragma unroll
-      for (int r = 0; r < N; ++r) {
-        step[r] = work[r * W + N];
-        g[r] = tot[N * (N + 1) / 2 + r];
-      }
-      if constexpr (N == 6) {
-        lmd->st.t[0] += step[0];
-        lmd->st.t[1] += step[1];
-        lmd->st.t[2] += step[2];
-        nos_host::Quat q;
-        q.w = lmd->st.q.w, q.x = lmd->st.q.x, q.y = lmd->st.q.y, q.z = lmd->st.q.z;
-        nos_host::RightMultiplyNormalize(&q, nos_host::ExpQuat(step + 3));
-        lmd->st.q.w = q.w, lmd->st.q.x = q.x, lmd->st.q.y = q.y, lmd->st.q.z = q.z;
-        double R[9];
-        nos_host::QuatToMatrix(q, R);
-#pragma unroll
-        for (int r = 0; r < 9; ++r) lmd->st.R[r] = R[r];
-      } else {
-        lmd->st.t[0] += step[0];
-        lmd->st.t[1] += step[1];
-        double c, sn;
-        sincos(step[2], &sn, &c);
-        const double a = lmd->st.R[0], b = lmd->st.R[1], dd = lmd->st.R[2], e = lmd->st.R[3];
-        lmd->st.R[0] = a * c + b * sn;  // linear <- linear * Rot2(dtheta)   (Isometry2d::rotate)
-        lmd->st.R[1] = b * c - a * sn;
-        lmd->st.R[2] = dd * c + e * sn;
-        lmd->st.R[3] = e * c - dd * sn;
-      }
-      if (nos_host::Norm<N>(step) < settings.parameter_tolerance || nos_host::Norm<N>(g) < settings.gradient_tolerance) {
-        lmd->st.done = 1;
-      } else {
-        const double lambda = lmd->st.lambda, previous = lmd->st.previous_cost;
-        if (settings.float_schedule) {
-          lmd->st.lambda = nos_host::NextLambdaFloat(lambda, cost, previous);
-          lmd->st.previous_cost = double(float(cost));
-        } else {
-          lmd->st.lambda = nos_host::NextLambda(lambda, cost, previous);
-          lmd->st.previous_cost = cost;
-        }
-        const int it = lmd->st.iteration + 1;
-        lmd->st.iteration = it;
-        if (it >= settings.max_iterations) lmd->st.done = 1;
-      }
+      const double inv_th = fast_rsqrt<double>(th2);  // 1 / theta
+      double sn, cs;
+      sincos(0.5 * (th2 * inv_th), &sn, &cs);
+      dw = cs;
+      kk = sn * inv_th;
     }
+    const double dx = kk * wx, dy = kk * wy, dz = kk * wz;
+    // q <- normalize(q (x) dq)
+    const double aw = lmd->st.q.w, ax = lmd->st.q.x, ay = lmd->st.q.y, az = lmd->st.q.z;
+    const double rw = aw * dw - ax * dx - ay * dy - az * dz;
+    const double rx = aw * dx + ax * dw + ay * dz - az * dy;
+    const double ry = aw * dy + ay * dw + az * dx - ax * dz;
+    const double rz = aw * dz + az * dw + ax * dy - ay * dx;
+    const double inv_n = fast_rsqrt<double>((rx * rx + ry * ry) + (rz * rz + rw * rw));
+    nos_host::Quat q;
+    q.w = rw * inv_n, q.x = rx * inv_n, q.y = ry * inv_n, q.z = rz * inv_n;
+    lmd->st.q.w = q.w, lmd->st.q.x = q.x, lmd->st.q.y = q.y, lmd->st.q.z = q.z;
+    double R[9];
+    nos_host::QuatToMatrix(q, R);
+#pragma unroll
+    for (int r = 0; r < 9; ++r) lmd->st.R[r] = R[r];
+  } else {
+    lmd->st.t[0] += step[0];
+    lmd->st.t[1] += step[1];
+    double c, sn;
+    if (step[2] * step[2] < 1.0 / 256.0) {  // |dtheta| < 1/16
+      double sc;
+      series_cos_sinc(step[2] * step[2], &c, &sc);
+      sn = step[2] * sc;
+    } else {
+      sincos(step[2], &sn, &c);
+    }
+    const double a = lmd->st.R[0], b = lmd->st.R[1], dd = lmd->st.R[2], e = lmd->st.R[3];
+    lmd->st.R[0] = a * c + b * sn;  // linear <- linear * Rot2(dtheta)   (Isometry2d::rotate)
+    lmd->st.R[1] = b * c - a * sn;
+    lmd->st.R[2] = dd * c + e * sn;
+    lmd->st.R[3] = e * c - dd * sn;
   }
-  wave_sync_lds();
+  if ((ptol > 0.0 && s2 < ptol * ptol) || (gtol > 0.0 && g2 < gtol * gtol)) {  // |step| < ptol || |g| < gtol
+    lmd->st.done = 1;
+  } else {
+    if (float_schedule) {
+      lmd->st.lambda = nos_host::NextLambdaFloat(lambda, cost, previous_cost);
+      lmd->st.previous_cost = double(float(cost));
+    } else {
+      lmd->st.lambda = nos_host::NextLambda(lambda, cost, previous_cost);
+      lmd->st.previous_cost = cost;
+    }
+    lmd->st.iteration = iteration + 1;
+    if (iteration + 1 >= max_iterations) lmd->st.done = 1;
+  }
+  NOS_STEP_TICK(1)
+}
+
+// The loop body; call with ONE lane.
+template <int NOUT>
+__device__ __forceinline__ void lm_step_lane(LdsDouble* tot, LdsLmDevice* lmd) {
+  lm_solve_lane<NOUT>(tot, lmd->st.lambda);
+  lm_finish_lane<NOUT>(tot, lmd);
 }
 
 // LDS address of a __shared__ object (the generic pointer HIP hands out, narrowed back to its address space)
@@ -1218,7 +1254,6 @@ __device__ __forceinline__ void finish_in_last_block(const double* partials, con
   // the loop state is requested now so that its latency hides behind the row sums
   const bool step_here = fin.lm != nullptr && fin.lm_step != 0;  // grid-uniform
   __shared__ double s_lmd_raw[(sizeof(LmDevice) + 7) / 8];       // the loop state while wave 0 advances it
-  __shared__ double s_work[kLmWorkDoubles];
   LmDevice& s_lmd = *reinterpret_cast<LmDevice*>(s_lmd_raw);
   constexpr int kLmdWords = int(sizeof(LmDevice) / sizeof(double));
   static_assert(sizeof(LmDevice) % sizeof(double) == 0, "LmDevice must be a whole number of doubles");
@@ -1254,7 +1289,7 @@ __device__ __forceinline__ void finish_in_last_block(const double* partials, con
   }
   red[slice][col] = s;
   __syncthreads();
-  __shared__ double s_tot[NOUT];
+  __shared__ double s_tot[kLmTotDoubles(NOUT)];
   double tot = 0.0;
   if (threadIdx.x < NOUT) {
 #pragma unroll
@@ -1286,13 +1321,13 @@ __device__ __forceinline__ void finish_in_last_block(const double* partials, con
       }
     }
     __syncthreads();
-    if (threadIdx.x < kWave && !exchange_failed) {  // wave 0, all lanes (exchange_failed is block-uniform)
+    if (threadIdx.x == 0 && !exchange_failed) {
       double* entry_host = fin.out_host;
       (void)entry_host;
       NOS_LM_STAMP(2);
-      lm_step_wave<NOUT>(lds_ptr(static_cast<const double*>(s_tot)), lds_ptr(&s_lmd), lds_ptr(s_work));
+      lm_step_lane<NOUT>(lds_ptr(s_tot), lds_ptr(&s_lmd));
       NOS_LM_STAMP(3);
-      if (threadIdx.x == 0) lm_publish(s_lmd.st, fin.lm, fin.out_host);
+      lm_publish(s_lmd.st, fin.lm, fin.out_host);
       NOS_LM_STAMP(4);
     }
   }
@@ -1315,7 +1350,9 @@ __device__ __forceinline__ void finish_in_last_block(const double* partials, con
 // Grid-stride over chunks of BLOCK*ITEMS correspondences.  `n_chunks * BLOCK * ITEMS`
 // must equal L.n_padded and the tile size must be a multiple of BLOCK*ITEMS (checked on
 // the host before launch).
-template <typename Problem, typename T, int ITEMS, int BLOCK, int MINW, bool NT, bool PREFETCH = false>
+// PREFETCH: 0 = the loads of a chunk, then its math; 1 = the NEXT chunk's loads are issued before the current chunk is
+// evaluated; 2 = two chunks ahead (twice the bytes in flight per lane while the item math runs).
+template <typename Problem, typename T, int ITEMS, int BLOCK, int MINW, bool NT, int PREFETCH = 0>
 __global__ __launch_bounds__(BLOCK, MINW) void assemble_kernel(TiledLayout L,
                                                               typename Problem::Params P,
                                                               uint32_t n_chunks,
@@ -1344,7 +1381,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void assemble_kernel(TiledLayout L,
   // is SLOWER that way on gfx950: 0.0942 → 0.1068 ms per launch at 10 M (profiles/r02_tune_f32_packed.txt; the guide's
   // constants table prices one v_pk_fma_f32 above two v_fma_f32).  Kept as a compile-time experiment (-DNOS_PACKED_F32).
 #ifdef NOS_PACKED_F32
-  constexpr bool kPacked = sizeof(T) == 4 && (ITEMS % 2 == 0) && !PREFETCH;
+  constexpr bool kPacked = sizeof(T) == 4 && (ITEMS % 2 == 0) && PREFETCH == 0;
 #else
   constexpr bool kPacked = false;
 #endif
@@ -1358,7 +1395,49 @@ __global__ __launch_bounds__(BLOCK, MINW) void assemble_kernel(TiledLayout L,
     i0 = uint64_t(c) * kChunk + uint64_t(threadIdx.x) * ITEMS;
     return (i0 >> L.tile_shift) * L.tile_stride + (i0 & L.tile_mask);
   };
-  if constexpr (PREFETCH) {
+  if constexpr (PREFETCH == 2) {
+    // two chunks ahead: while chunk c is evaluated the loads of c + G and c + 2G are in flight
+    T xa[kF][ITEMS], xb[kF][ITEMS];
+    uint32_t c = blockIdx.x;
+    uint64_t i0 = 0, i1 = 0;
+    if (c < n_chunks) {
+      const uint64_t off = chunk_offset(c, i0);
+#pragma unroll
+      for (int f = 0; f < kF; ++f) load_items<T, ITEMS, NT>(base + off + uint64_t(f) * L.field_stride, xa[f]);
+    }
+    if (c + gridDim.x < n_chunks) {
+      const uint64_t off = chunk_offset(c + gridDim.x, i1);
+#pragma unroll
+      for (int f = 0; f < kF; ++f) load_items<T, ITEMS, NT>(base + off + uint64_t(f) * L.field_stride, xb[f]);
+    }
+    if (lm_prologue(fin, P)) return;  // grid-uniform
+    for (; c < n_chunks; c += gridDim.x) {
+      T xc[kF][ITEMS];
+      uint64_t i2 = 0;
+      const uint32_t cn = c + 2 * gridDim.x;
+      if (cn < n_chunks) {
+        const uint64_t off = chunk_offset(cn, i2);
+#pragma unroll
+        for (int f = 0; f < kF; ++f) load_items<T, ITEMS, NT>(base + off + uint64_t(f) * L.field_stride, xc[f]);
+      }
+#pragma unroll
+      for (int it = 0; it < ITEMS; ++it) {
+        T xi[kF];
+#pragma unroll
+        for (int f = 0; f < kF; ++f) xi[f] = xa[f][it];
+        Problem::item(xi, P, (i0 + it) < L.n, acc);
+      }
+#pragma unroll
+      for (int f = 0; f < kF; ++f)
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+          xa[f][it] = xb[f][it];
+          xb[f][it] = xc[f][it];
+        }
+      i0 = i1;
+      i1 = i2;
+    }
+  } else if constexpr (PREFETCH == 1) {
     // software pipelined: the 15 loads of the NEXT chunk are issued before the current chunk is
     // evaluated, so a wave always has a chunk in flight while it computes
     T xa[kF][ITEMS];
@@ -1484,8 +1563,7 @@ __global__ __launch_bounds__(BLOCK) void solve_single_block_kernel(TiledLayout L
   const T* __restrict__ base = static_cast<const T*>(L.base);
   __shared__ double s_lm_raw[(sizeof(LmDevice) + 7) / 8];  // raw storage: the struct has default member initialisers
   LmDevice& s_lm = *reinterpret_cast<LmDevice*>(s_lm_raw);
-  __shared__ double s_sum[kOut];
-  __shared__ double s_work[kLmWorkDoubles];
+  __shared__ double s_sum[kLmTotDoubles(kOut)];
   if (threadIdx.x == 0) s_lm = *lm;
   __syncthreads();
   int executed = 0;
@@ -1524,10 +1602,10 @@ __global__ __launch_bounds__(BLOCK) void solve_single_block_kernel(TiledLayout L
     for (int k = 0; k < kOut; ++k) dacc[k] = double(acc[k]);
     block_reduce_store<kOut, BLOCK>(dacc, s_sum, false);
     __syncthreads();
-    if (threadIdx.x < kWave) {  // wave 0 advances the loop (nos_host::LmAdvance*, wave-parallel)
-      if (threadIdx.x == 0 && cost_history != nullptr && executed < history_capacity)
+    if (threadIdx.x == 0) {
+      if (cost_history != nullptr && executed < history_capacity)
         __hip_atomic_store(cost_history + executed, s_sum[kOut - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      lm_step_wave<kOut>(lds_ptr(static_cast<const double*>(s_sum)), lds_ptr(&s_lm), lds_ptr(s_work));
+      lm_step_lane<kOut>(lds_ptr(s_sum), lds_ptr(&s_lm));
     }
     ++executed;
     __syncthreads();
@@ -1668,10 +1746,9 @@ __global__ __launch_bounds__(BLOCK) void solve_cluster_kernel(TiledLayout L, typ
   __shared__ int s_flag;  // 0 go on, 1 loop finished, 2 abort
   __shared__ int s_fast;  // 1 once every group has been seen to sit on one XCD: stage-1 units then stay in that XCD's L2
   __shared__ double red[kSlices][kCols];
-  __shared__ double s_tot[kOut];
+  __shared__ double s_tot[kLmTotDoubles(kOut)];
   __shared__ double s_pose[12];
   __shared__ double s_lmd_raw[(sizeof(LmDevice) + 7) / 8];  // this workgroup's copy of the loop state and settings
-  __shared__ double s_work[kLmWorkDoubles];
   LmDevice& s_lmd = *reinterpret_cast<LmDevice*>(s_lmd_raw);
   nos_host::LmState& s_state = s_lmd.st;
 
@@ -1729,6 +1806,9 @@ __global__ __launch_bounds__(BLOCK) void solve_cluster_kernel(TiledLayout L, typ
       for (int f = 0; f < kF; ++f) resident[(size_t(j - RI) * kF + f) * BLOCK + threadIdx.x] = xi[f];
     }
   }
+#ifdef NOS_LM_TIMING
+  if (threadIdx.x < 4) s_step_cycles[threadIdx.x] = 0ull;
+#endif
   if (threadIdx.x == 0) {
     s_lmd.settings = lm->settings;  // constant during the launch
     s_state = lm->st;  // written by lm_init_kernel before this launch
@@ -1994,13 +2074,15 @@ __global__ __launch_bounds__(BLOCK) void solve_cluster_kernel(TiledLayout L, typ
     }  // PROTO
     {
       NOS_RES_STAMP(3)  // rows → sums
-      if (threadIdx.x < kWave) {  // wave 0 of EVERY workgroup advances its own copy of the loop (identical bits everywhere)
-        if (threadIdx.x == 0 && blockIdx.x == 0 && cost_history != nullptr && executed < history_capacity)
+      if (threadIdx.x == 0) {  // lane 0 of EVERY workgroup advances its own copy of the loop (identical bits everywhere)
+        if (blockIdx.x == 0 && cost_history != nullptr && executed < history_capacity)
           __hip_atomic_store(cost_history + executed, s_tot[kOut - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        lm_step_wave<kOut>(lds_ptr(static_cast<const double*>(s_tot)), lds_ptr(&s_lmd), lds_ptr(s_work));
-        if (threadIdx.x < 9) s_pose[threadIdx.x] = s_state.R[threadIdx.x];
-        if (threadIdx.x < 3) s_pose[9 + threadIdx.x] = s_state.t[threadIdx.x];
-        if (threadIdx.x == 0) s_flag = s_state.done != 0 ? 1 : 0;
+        lm_step_lane<kOut>(lds_ptr(s_tot), lds_ptr(&s_lmd));
+#pragma unroll
+        for (int k = 0; k < 9; ++k) s_pose[k] = s_state.R[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) s_pose[9 + k] = s_state.t[k];
+        s_flag = s_state.done != 0 ? 1 : 0;
       }
     }
     ++executed;
@@ -2009,10 +2091,14 @@ __global__ __launch_bounds__(BLOCK) void solve_cluster_kernel(TiledLayout L, typ
     NOS_RES_STAMP(4)  // LM step + barrier
   }
 #ifdef NOS_LM_TIMING
-  if (blockIdx.x == 0 && threadIdx.x == 0 && entry_host != nullptr)
+  if (blockIdx.x == 0 && threadIdx.x == 0 && entry_host != nullptr) {
     for (int k = 0; k < 5; ++k)
       __hip_atomic_store(entry_host + 50 + k, double(tq[k]) / double(executed > 0 ? executed : 1), __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_SYSTEM);
+    for (int k = 0; k < 3; ++k)
+      __hip_atomic_store(entry_host + 56 + k, double(s_step_cycles[k]) / double(executed > 0 ? executed : 1), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 #endif
   // workgroup 0 reports (on abort nobody does: the host sees the missing sequence word)
   if (s_flag == 1 && blockIdx.x == 0) {
@@ -2237,9 +2323,8 @@ __attribute__((unused)) static __global__ void lm_init_kernel(LmDevice* lm, LmIn
 template <int NOUT>
 __global__ __launch_bounds__(64) void lm_step_kernel(const double* __restrict__ sums, LmDevice* lm, double* entry_host,
                                                      unsigned long long* seq_host, unsigned long long seq) {
-  __shared__ double s_tot[NOUT];
+  __shared__ double s_tot[kLmTotDoubles(NOUT)];
   __shared__ double s_lmd_raw[(sizeof(LmDevice) + 7) / 8];
-  __shared__ double s_work[kLmWorkDoubles];
   LmDevice& s_lmd = *reinterpret_cast<LmDevice*>(s_lmd_raw);
   const int done = *reinterpret_cast<const volatile int*>(&lm->st.done);  // loop finished earlier: forward seq only
   if (done == 0) {
@@ -2254,8 +2339,10 @@ __global__ __launch_bounds__(64) void lm_step_kernel(const double* __restrict__ 
       s_lmd.settings = lm->settings;
     }
     __syncthreads();
-    lm_step_wave<NOUT>(lds_ptr(static_cast<const double*>(s_tot)), lds_ptr(&s_lmd), lds_ptr(s_work));  // one wave
-    if (threadIdx.x == 0) lm_publish(s_lmd.st, lm, entry_host);
+    if (threadIdx.x == 0) {
+      lm_step_lane<NOUT>(lds_ptr(s_tot), lds_ptr(&s_lmd));
+      lm_publish(s_lmd.st, lm, entry_host);
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (threadIdx.x == 0 && seq_host != nullptr) {

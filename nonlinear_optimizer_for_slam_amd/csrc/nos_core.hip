@@ -5,6 +5,8 @@
 // fails with NOS_ERR_NO_DEVICE / NOS_ERR_HIP.
 #include "nos_internal.hpp"
 
+#include <cxxabi.h>
+
 namespace nosd {
 
 namespace {
@@ -130,6 +132,10 @@ size_t layout_elems(const nos::TiledLayout& L, int n_fields) {
 // is the default).
 constexpr int kNumVariants = 11;
 
+// Host function of the hot-path kernel the current thread launched last (launch_variant / launch_single); copied into
+// the device slot by launch_assemble_raw so that nos_ctx_last_kernel can name the instantiation that actually ran.
+thread_local const void* t_last_kernel = nullptr;
+
 template <typename Problem, typename T, int ITEMS, int BLOCK, int MINW, bool PREFETCH = false>
 int launch_variant(const nos::TiledLayout& L, const typename Problem::Params& P, int grid_cap, int num_cus_hint,
                    bool nt, double* partials, const nos::FusedFinal& fin_in, hipStream_t stream, int* rows_out) {
@@ -146,12 +152,10 @@ int launch_variant(const nos::TiledLayout& L, const typename Problem::Params& P,
   nos::FusedFinal fin = fin_in;
   // write-through hand-off only in the geometry it is documented valid for: at most one workgroup per CU
   fin.write_through = (fin.counter != nullptr && grid <= num_cus_hint && fin_in.write_through != 0) ? 1 : 0;  // in: allowed (settings.sc1)
-  if (nt)
-    hipLaunchKernelGGL((nos::assemble_kernel<Problem, T, ITEMS, BLOCK, MINW, true, PREFETCH>), dim3(grid), dim3(BLOCK), 0,
-                       stream, L, P, n_chunks, partials, fin);
-  else
-    hipLaunchKernelGGL((nos::assemble_kernel<Problem, T, ITEMS, BLOCK, MINW, false, PREFETCH>), dim3(grid), dim3(BLOCK), 0,
-                       stream, L, P, n_chunks, partials, fin);
+  const auto kernel = nt ? nos::assemble_kernel<Problem, T, ITEMS, BLOCK, MINW, true, PREFETCH>
+                         : nos::assemble_kernel<Problem, T, ITEMS, BLOCK, MINW, false, PREFETCH>;
+  t_last_kernel = reinterpret_cast<const void*>(kernel);
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLOCK), 0, stream, L, P, n_chunks, partials, fin);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(NOS_ERR_HIP, "assemble launch failed: %s", hipGetErrorString(e));
   *rows_out = grid;
@@ -263,6 +267,7 @@ int launch_single(const nos::TiledLayout& L, const typename Problem::Params& P, 
     if (size_t(a.stream_chunks) * kChunk != L.n_padded) return fail(NOS_ERR_INVALID_ARGUMENT, "streaming solve: chunk count does not match the layout");
     const auto kernel = a.nt ? nos::solve_cluster_kernel<Problem, T, kBlock, 0, 0, 1, kSI, kSPF, true>
                              : nos::solve_cluster_kernel<Problem, T, kBlock, 0, 0, 1, kSI, kSPF, false>;
+    t_last_kernel = reinterpret_cast<const void*>(kernel);
     hipLaunchKernelGGL(kernel, dim3(a.cluster_blocks), dim3(kBlock), 0, stream, L, P, a.partials, a.lm, a.ctl, a.history,
                        a.history_capacity, a.entry, a.seq_host, a.seq, uint32_t(a.stream_chunks) | (a.stage1_sc1 ? 0x80000000u : 0u));
     hipError_t e = hipGetLastError();
@@ -287,6 +292,7 @@ int launch_single(const nos::TiledLayout& L, const typename Problem::Params& P, 
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(dyn_bytes));
       if (ea != hipSuccess) return fail(NOS_ERR_HIP, "resident solve: %zu bytes of LDS refused: %s", dyn_bytes, hipGetErrorString(ea));
     }
+    t_last_kernel = reinterpret_cast<const void*>(kernel);
     hipLaunchKernelGGL(kernel, dim3(a.cluster_blocks), dim3(kBlock), dyn_bytes, stream, L, P, a.partials, a.lm, a.ctl,
                        a.history, a.history_capacity, a.entry, a.seq_host, a.seq,
                        uint32_t(a.items_per_lane) | (a.stage1_sc1 ? 0x80000000u : 0u));
@@ -295,6 +301,7 @@ int launch_single(const nos::TiledLayout& L, const typename Problem::Params& P, 
     return NOS_OK;
   }
   const uint32_t n_chunks = uint32_t((std::max<uint64_t>(L.n, 1) + kBlock - 1) / kBlock);  // pads beyond are never read
+  t_last_kernel = reinterpret_cast<const void*>(&nos::solve_single_block_kernel<Problem, T, kBlock>);
   hipLaunchKernelGGL((nos::solve_single_block_kernel<Problem, T, kBlock>), dim3(1), dim3(kBlock), 0, stream, L, P, n_chunks, a.lm,
                      a.history, a.history_capacity, a.entry, a.seq_host, a.seq);
   hipError_t e = hipGetLastError();
@@ -364,8 +371,19 @@ int launch_assemble(const nos_dataset* ds, const Shard& sh, const Request& rq, d
   return NOS_OK;
 }
 
+int launch_assemble_inner(const nos_dataset* ds, const Shard& sh, const Request& rq, double* partials,
+                          const nos::FusedFinal& fin_in, hipStream_t stream, int* rows_out, const SingleBlockArgs* single);
+
 int launch_assemble_raw(const nos_dataset* ds, const Shard& sh, const Request& rq, double* partials,
                         const nos::FusedFinal& fin_in, hipStream_t stream, int* rows_out, const SingleBlockArgs* single) {
+  t_last_kernel = nullptr;
+  const int rc = launch_assemble_inner(ds, sh, rq, partials, fin_in, stream, rows_out, single);
+  if (rc == NOS_OK && t_last_kernel != nullptr) ds->ctx->slots[sh.slot].last_kernel = t_last_kernel;
+  return rc;
+}
+
+int launch_assemble_inner(const nos_dataset* ds, const Shard& sh, const Request& rq, double* partials,
+                          const nos::FusedFinal& fin_in, hipStream_t stream, int* rows_out, const SingleBlockArgs* single) {
   const nos_ctx* ctx = ds->ctx;
   nos::FusedFinal fin = fin_in;
   fin.write_through = ctx->settings.sc1;  // "allowed"; the launcher keeps it only for the geometry it is valid for
@@ -815,6 +833,8 @@ int lm_solve(nos_dataset* ds, const Request& rq, const nos_lm_options* opt, doub
       fprintf(stderr, "[resident-timing] %d blocks x %d items/lane (0 = streamed), %d iterations; workgroup 0, us per iteration: item math %.2f, "
               "block reduce %.2f, drain+arrive+wait %.2f, rows->sums %.2f, LM step+barrier %.2f\n", cl.cluster_blocks,
               cl.items_per_lane, executed, e[50] * 0.01, e[51] * 0.01, e[52] * 0.01, e[53] * 0.01, e[54] * 0.01);
+      fprintf(stderr, "[resident-timing]    inside the step, shader-clock cycles per iteration: elimination %.0f, back substitution %.0f, "
+              "lane 0 (pose update, tests, schedule) %.0f\n", e[56], e[57], e[58]);
 #endif
       if (slot.prof_on && slot.prof_every == 0) slot.prof_launches += executed;  // bracket profiling counts passes over the data
       if (opt->cost_history != nullptr)
@@ -1623,6 +1643,25 @@ int nos_runtime_info(char* buf, size_t capacity) {
                          (!rccl_dir.empty() && rccl_dir == hip_dir) ? "true" : "false",
                          (build / 100000 == runtime / 100000) ? "true" : "false");
   if (n < 0 || size_t(n) >= capacity) return fail(NOS_ERR_INVALID_ARGUMENT, "buffer too small");
+  return NOS_OK;
+}
+
+// Symbol (demangled) of the hot-path kernel launched last on `shard` of this context — the instantiation the library
+// chose (problem, element type, loss, launch geometry / loop form), as rocprofv3 will list it.
+int nos_ctx_last_kernel(const nos_ctx* ctx, int shard, char* buf, size_t capacity) {
+  if (!ctx || !buf || capacity == 0) return fail(NOS_ERR_INVALID_ARGUMENT, "ctx / buf is NULL");
+  nosd::CtxGuard guard_(ctx);
+  if (shard < 0 || size_t(shard) >= ctx->slots.size()) return fail(NOS_ERR_INVALID_ARGUMENT, "bad shard index");
+  buf[0] = 0;
+  const DeviceSlot& slot = ctx->slots[shard];
+  if (slot.last_kernel == nullptr) return NOS_OK;
+  NOS_HIP_CHECK(hipSetDevice(slot.device));
+  const char* mangled = hipKernelNameRefByPtr(slot.last_kernel, slot.stream);
+  if (mangled == nullptr) return fail(NOS_ERR_HIP, "hipKernelNameRefByPtr returned NULL");
+  int status = 0;
+  char* dem = abi::__cxa_demangle(mangled, nullptr, nullptr, &status);
+  snprintf(buf, capacity, "%s", (status == 0 && dem) ? dem : mangled);
+  free(dem);
   return NOS_OK;
 }
 

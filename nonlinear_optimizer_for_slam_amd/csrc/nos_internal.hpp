@@ -113,6 +113,7 @@ struct DeviceSlot {
   std::vector<PoolEntry> pool;
   size_t pool_bytes = 0;
   bool pool_enabled = true;  // Settings::pool
+  const void* last_kernel = nullptr;  // host function of the hot-path kernel launched last on this device (nos_ctx_last_kernel)
   bool cluster_gave_up = false;  // the last one-launch solve on this device timed out waiting for its grid (shared GPU)
   std::chrono::steady_clock::time_point cluster_gave_up_at{};
   std::vector<hipEvent_t> prof_events;

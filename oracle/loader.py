@@ -263,6 +263,27 @@ def avx_reproj_accumulate(planes_f32, R, t, intr, loss=None, threads=1):
                      threads)
 
 
+def avx_ndt6_accumulate_f64(planes, R, t, loss=None, threads=1):
+    """4-lane fp64 AVX2/FMA restatement of SolveDouble's inner loop (MDM/..._analytic_simd_various.cc:42-134): the
+    same-precision CPU baseline of the fp64 headline.  planes: [15, n] float64; floor(n/4)*4 items are used."""
+    p = np.ascontiguousarray(planes, dtype=np.float64)
+    assert p.ndim == 2 and p.shape[0] == 15
+    arr = (c_double_p * 15)()
+    for k in range(15):
+        arr[k] = p[k].ctypes.data_as(c_double_p)
+    R = _vec(R, 9)
+    t = _vec(t, 3)
+    out = np.zeros(28)
+    l = make_loss(loss)
+    fn = avx().oracle_avx_ndt6_accumulate_f64
+    fn.restype = ctypes.c_int
+    rc = fn(ctypes.c_size_t(p.shape[1]), arr, R.ctypes.data_as(c_double_p), t.ctypes.data_as(c_double_p),
+            ctypes.byref(l), ctypes.c_int(threads), out.ctypes.data_as(c_double_p))
+    if rc != 0:
+        raise RuntimeError("oracle_avx_ndt6_accumulate_f64 failed: %d" % rc)
+    return out
+
+
 def avx_ndt6_accumulate(planes_f32, R, t, loss=None, threads=1):
     """AVX2/FMA fp32 baseline.  planes_f32: [15, n] float32, n multiple of 8 is processed
     (floor(n/8)*8 like the reference)."""

@@ -17,6 +17,18 @@
  *   oracle_avx_ndt3_accumulate    MDM/mahalanobis_distance_minimizer_analytic_3dof_simd.cc:85-158 (+ lane sums :160-177)
  *   oracle_avx_reproj_accumulate  REM/reprojection_error_minimizer_analytic_simd.cc:55-138 (+ lane sums :140-157):
  *                                 depth mask `Xw.z > 0` multiplying the weight (:66,92), 1/fx evaluated in float (:29-30)
+ *
+ * The SAME-PRECISION baseline of the fp64 headline (round 3):
+ *   oracle_avx_ndt6_accumulate_f64  the inner loop of MahalanobisDistanceMinimizerAnalyticSIMDVarious::SolveDouble
+ *                                 (MDM/..._analytic_simd_various.cc:42-134; lane sums :135-149): 4-lane fp64 (the in-tree
+ *                                 ScalarD = __m256d, NO/simd_helper/simd_scalar_amd.h), 4 correspondences per step, only
+ *                                 floor(N/4)*4 used (:41-43), pw = R p + t, e, r = S e, M = -R [p]x (:69-77), S M (:78),
+ *                                 loss per lane through the scalar virtual (:107-121), g += (J^T r) w (:124),
+ *                                 H(ii, jj) += w (J0i J0j + J1i J1j + J2i J2j) (:127-133), cost += loss (:135).
+ *                                 The reference GATHERS its four 304-byte records into lanes every iteration (:48-58) and
+ *                                 runs on one thread; this restatement reads planar fp64 planes (the CPU is spared the
+ *                                 gather: an upper bound of that variant's speed) and offers the 6-DoF SIMD class's thread
+ *                                 partition on multiples of 4 (an extrapolation, stated wherever it is reported).
  */
 #include <immintrin.h>
 #include <math.h>
@@ -245,6 +257,94 @@ static void avx_range_reproj(avx_job* job) {
   job->out28[27] = (double)hsum8(cost);
 }
 
+typedef struct avx_job_f64 {
+  const double* const* planes;
+  size_t begin, end; /* multiples of 4 */
+  double R[9], t[3];
+  oracle_loss loss;
+  double out28[28];
+} avx_job_f64;
+
+static inline double hsum4(__m256d v) {
+  double buf[4];
+  _mm256_storeu_pd(buf, v);
+  return buf[0] + buf[1] + buf[2] + buf[3]; /* `buf[0] + buf[1] + buf[2] + buf[3]`, MDM/..._simd_various.cc:139,144,147 */
+}
+
+/* MDM/mahalanobis_distance_minimizer_analytic_simd_various.cc:42-134 (SolveDouble's inner loop), 4-lane fp64.  The
+ * helper's operators are plain mul / add / sub on __m256d (NO/simd_helper/simd_scalar_amd.h: no fused forms), what the
+ * compiler then contracts under the reference's -O2 -march=native is its business; here the products feed explicit FMAs
+ * like the fp32 restatement above (both are timing baselines, checked against the scalar oracle to 1e-12). */
+static void avx_range_f64(avx_job_f64* job) {
+  __m256d R[9], t[3], H[21], g[6], cost;
+  const double* const* pl = job->planes;
+  size_t i;
+  int a, b, k;
+  for (k = 0; k < 9; ++k) R[k] = _mm256_set1_pd(job->R[k]);
+  for (k = 0; k < 3; ++k) t[k] = _mm256_set1_pd(job->t[k]);
+  for (k = 0; k < 21; ++k) H[k] = _mm256_setzero_pd();
+  for (k = 0; k < 6; ++k) g[k] = _mm256_setzero_pd();
+  cost = _mm256_setzero_pd();
+  for (i = job->begin; i < job->end; i += 4) {
+    __m256d p[3], mu[3], S[9], e[3], r[3], M[9], J[18], s, rho, w;
+    for (k = 0; k < 3; ++k) p[k] = _mm256_loadu_pd(pl[k] + i);
+    for (k = 0; k < 3; ++k) mu[k] = _mm256_loadu_pd(pl[3 + k] + i);
+    for (k = 0; k < 9; ++k) S[k] = _mm256_loadu_pd(pl[6 + k] + i);
+    for (a = 0; a < 3; ++a) {
+      __m256d pw = _mm256_fmadd_pd(
+          R[3 * a], p[0], _mm256_fmadd_pd(R[3 * a + 1], p[1], _mm256_fmadd_pd(R[3 * a + 2], p[2], t[a])));
+      e[a] = _mm256_sub_pd(pw, mu[a]);
+    }
+    for (a = 0; a < 3; ++a)
+      r[a] = _mm256_fmadd_pd(S[3 * a], e[0],
+                             _mm256_fmadd_pd(S[3 * a + 1], e[1], _mm256_mul_pd(S[3 * a + 2], e[2])));
+    for (a = 0; a < 3; ++a) { /* minus_R_skewp, :69-77 */
+      M[3 * a + 0] = _mm256_fmsub_pd(R[3 * a + 2], p[1], _mm256_mul_pd(R[3 * a + 1], p[2]));
+      M[3 * a + 1] = _mm256_fmsub_pd(R[3 * a + 0], p[2], _mm256_mul_pd(R[3 * a + 2], p[0]));
+      M[3 * a + 2] = _mm256_fmsub_pd(R[3 * a + 1], p[0], _mm256_mul_pd(R[3 * a + 0], p[1]));
+    }
+    for (a = 0; a < 3; ++a)
+      for (b = 0; b < 3; ++b) {
+        J[6 * a + b] = S[3 * a + b];
+        J[6 * a + 3 + b] = _mm256_fmadd_pd(
+            S[3 * a], M[b], _mm256_fmadd_pd(S[3 * a + 1], M[3 + b], _mm256_mul_pd(S[3 * a + 2], M[6 + b])));
+      }
+    s = _mm256_fmadd_pd(r[0], r[0], _mm256_fmadd_pd(r[1], r[1], _mm256_mul_pd(r[2], r[2])));
+    rho = s;
+    w = _mm256_set1_pd(1.0);
+    if (job->loss.kind != 0) { /* per lane through the scalar virtual, :107-121 */
+      double sb[4], lb[4], wb[4];
+      _mm256_storeu_pd(sb, s);
+      for (k = 0; k < 4; ++k) oracle_loss_evaluate(&job->loss, sb[k], &lb[k], &wb[k]);
+      rho = _mm256_loadu_pd(lb);
+      w = _mm256_loadu_pd(wb);
+    }
+    for (a = 0; a < 6; ++a)
+      g[a] = _mm256_add_pd(
+          g[a],
+          _mm256_mul_pd(_mm256_fmadd_pd(J[a], r[0], _mm256_fmadd_pd(J[6 + a], r[1], _mm256_mul_pd(J[12 + a], r[2]))),
+                        w));
+    k = 0;
+    for (a = 0; a < 6; ++a)
+      for (b = a; b < 6; ++b) {
+        H[k] = _mm256_add_pd(
+            H[k], _mm256_mul_pd(w, _mm256_fmadd_pd(J[a], J[b],
+                                                   _mm256_fmadd_pd(J[6 + a], J[6 + b],
+                                                                   _mm256_mul_pd(J[12 + a], J[12 + b])))));
+        ++k;
+      }
+    cost = _mm256_add_pd(cost, rho);
+  }
+  for (k = 0; k < 21; ++k) job->out28[k] = hsum4(H[k]);
+  for (k = 0; k < 6; ++k) job->out28[21 + k] = hsum4(g[k]);
+  job->out28[27] = hsum4(cost);
+}
+
+static void* avx_thread_f64(void* arg) {
+  avx_range_f64((avx_job_f64*)arg);
+  return NULL;
+}
+
 static void* avx_thread(void* arg) {
   avx_job* job = (avx_job*)arg;
   if (job->kind == 1)
@@ -348,4 +448,49 @@ int oracle_avx_reproj_accumulate(size_t n, const float* const planes[5], const d
                                  const double t[3], const double intr[4], const oracle_loss* loss,
                                  int threads, double out28[28]) {
   return avx_run(2, n, planes, R, 9, t, 3, intr, loss, threads, out28, 28);
+}
+
+/* floor(n/4)*4 items (MDM/..._simd_various.cc:41-43) in `threads` contiguous batches of floor(floor(n/4)/threads)*4 — the
+ * 6-DoF SIMD class's partition rule (MDM/..._analytic_simd.cc:57-69) on this variant's stride; threads = 1 is what the
+ * reference's SolveDouble does. */
+int oracle_avx_ndt6_accumulate_f64(size_t n, const double* const planes[15], const double R[9], const double t[3],
+                                   const oracle_loss* loss, int threads, double out28[28]) {
+  const size_t num_stride = n / 4;
+  avx_job_f64* jobs;
+  pthread_t* tids;
+  int i, k;
+  if (threads < 1) threads = 1;
+  jobs = (avx_job_f64*)calloc((size_t)threads, sizeof(avx_job_f64));
+  tids = (pthread_t*)calloc((size_t)threads, sizeof(pthread_t));
+  if (!jobs || !tids) {
+    free(jobs);
+    free(tids);
+    return 1;
+  }
+  {
+    const size_t num_batch = (threads == 1) ? num_stride * 4 : (num_stride / (size_t)threads) * 4;
+    for (i = 0; i < threads; ++i) {
+      size_t b = (size_t)i * num_batch, e = ((size_t)i + 1) * num_batch;
+      if (e > num_stride * 4) e = num_stride * 4;
+      if (b > e) b = e;
+      jobs[i].planes = planes;
+      jobs[i].begin = b;
+      jobs[i].end = e;
+      for (k = 0; k < 9; ++k) jobs[i].R[k] = R[k];
+      for (k = 0; k < 3; ++k) jobs[i].t[k] = t[k];
+      if (loss) jobs[i].loss = *loss;
+    }
+  }
+  if (threads == 1) {
+    avx_thread_f64(&jobs[0]);
+  } else {
+    for (i = 0; i < threads; ++i) pthread_create(&tids[i], NULL, avx_thread_f64, &jobs[i]);
+    for (i = 0; i < threads; ++i) pthread_join(tids[i], NULL);
+  }
+  memset(out28, 0, 28 * sizeof(double));
+  for (i = 0; i < threads; ++i)
+    for (k = 0; k < 28; ++k) out28[k] += jobs[i].out28[k];
+  free(jobs);
+  free(tids);
+  return 0;
 }

@@ -168,6 +168,23 @@ def test_avx_baseline_matches_scalar_oracle(oracle):
         helpers.assert_normal_equations_close(got, want, 6, 5e-4)
 
 
+@pytest.mark.parametrize("loss", [None, ("exponential", 1.0, 1.0), ("huber", 1.0)])
+def test_fp64_avx_baseline_matches_scalar_oracle(oracle, loss):
+    """The same-precision CPU baseline of the fp64 headline: SolveDouble's 4-lane fp64 inner loop
+    (MDM/..._analytic_simd_various.cc:42-134) against the scalar class's loop, to 1e-12, including the floor(N/4)*4 rule
+    and the thread partition on multiples of 4."""
+    planes = synth.ndt_planes(40_003, 900)
+    R = helpers.rot_xyz(0.01, -0.02, 0.05)
+    t = np.array([-0.1, 0.05, 0.2])
+    n = planes.shape[1]
+    for threads in (1, 3, 8):
+        keep = (n // 4) * 4 if threads == 1 else threads * ((n // 4) // threads) * 4
+        want = oracle.ndt6_accumulate(planes[:, :keep], R, t, loss)
+        got = oracle.avx_ndt6_accumulate_f64(planes, R, t, loss, threads=threads)
+        helpers.assert_normal_equations_close(got, want, 6, 1e-12)
+    assert np.all(oracle.avx_ndt6_accumulate_f64(planes[:, :3], R, t, loss) == 0.0)  # fewer than one stride: nothing
+
+
 def test_edge_cases_empty_and_single(oracle):
     planes = synth.ndt_planes(1, 1)
     out0 = oracle.ndt6_accumulate(planes[:, :0], np.eye(3), np.zeros(3), None)

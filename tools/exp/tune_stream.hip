@@ -21,6 +21,27 @@ using namespace nos;
     }                                                                              \
   } while (0)
 
+// Same loads, (almost) no arithmetic: what the launch costs when only the memory system works — the floor of the geometry
+template <typename T>
+struct StreamParams {
+  T R[9];
+  T t[3];
+  T la, lb, lc;
+};
+template <typename T>
+__device__ __forceinline__ void set_pose(StreamParams<T>&, const nos::LmDevice*) {}  // found by ADL from lm_prologue
+
+template <typename T, int FIELDS>
+struct StreamOnlyProblem {
+  static constexpr int kFields = FIELDS;
+  static constexpr int kOut = 28;
+  using Params = StreamParams<T>;
+  __device__ static __forceinline__ void item(const T (&x)[FIELDS], const Params&, bool, T (&acc)[28]) {
+#pragma unroll
+    for (int f = 0; f < FIELDS; ++f) acc[f] += x[f];
+  }
+};
+
 struct Bench {
   TiledLayout L{};
   double* partials = nullptr;
@@ -30,7 +51,7 @@ struct Bench {
   int num_cus = 256;
 };
 
-template <typename Problem, typename T, int ITEMS, int BLOCK, int MINW, bool NT, bool PF>
+template <typename Problem, typename T, int ITEMS, int BLOCK, int MINW, bool NT, int PF>
 void run(const Bench& b, const typename Problem::Params& P, int bpc, double* ref, const char* tag) {
   constexpr uint32_t kChunk = BLOCK * ITEMS;
   if (b.L.n_padded % kChunk != 0) {
@@ -133,7 +154,104 @@ void bench_reproj(size_t n, int num_cus) {
   RUN(2, 512, 4, true, 2);
   RUN(8, 512, 2, false, 1);
   RUN(8, 256, 2, false, 2);
+  RUN(8, 256, 2, false, 1);
+  RUN(2, 512, 2, 2, 1);
 #undef RUN
+  {  // the floor of the geometry: the same loads with no arithmetic
+    using PS = StreamOnlyProblem<T, 5>;
+    typename PS::Params Q{};
+    double r2[28] = {0};
+    run<PS, T, 1, 512, 3, false, 0>(b, Q, 1, r2, "stream-only items=1 block=512");
+    double r3[28] = {0};
+    run<PS, T, 2, 512, 2, false, 0>(b, Q, 1, r3, "stream-only items=2 block=512");
+    double r4[28] = {0};
+    run<PS, T, 8, 512, 2, false, 0>(b, Q, 1, r4, "stream-only items=8 block=512");
+    double r5[28] = {0};
+    run<PS, T, 4, 512, 2, false, 1>(b, Q, 1, r5, "stream-only items=4 block=512 pf=1");
+  }
+  // size sweep of two geometries: per-launch time = fixed part + n x slope
+  for (size_t m : {size_t(131072), size_t(524288), size_t(1048576), size_t(2000000), size_t(4000000), size_t(8000000)}) {
+    if (m > n * 4) break;
+  }
+}
+
+template <typename T>
+void bench_ndt6(size_t n, int num_cus, int tile_log2) {
+  using PE = Ndt6Problem<T, 1>;  // exponential
+  std::mt19937_64 rng(20250912);
+  std::normal_distribution<double> N01(0.0, 1.0);
+  Bench b;
+  b.num_cus = num_cus;
+  b.reps = 60;
+  const size_t pad = 8192;
+  b.L.n = n;
+  b.L.n_padded = (n + pad - 1) / pad * pad;
+  if (tile_log2 > 0) {
+    const size_t tile = size_t(1) << tile_log2;
+    b.L.tile_stride = tile * 15;
+    b.L.field_stride = tile;
+    b.L.tile_shift = uint32_t(tile_log2);
+    b.L.tile_mask = uint32_t(tile - 1);
+  } else {
+    b.L.tile_stride = 0;
+    b.L.field_stride = b.L.n_padded + 1088;
+    b.L.tile_shift = 40;
+    b.L.tile_mask = 0xFFFFFFFFu;
+  }
+  const size_t elems = (b.L.tile_stride == 0 ? b.L.field_stride : b.L.n_padded) * 15;
+  std::vector<T> h(elems);
+  for (size_t i = 0; i < elems; ++i) h[i] = T(0.3 * N01(rng));  // values only steer exp(): any finite data times the same
+  T* d = nullptr;
+  CK(hipMalloc(reinterpret_cast<void**>(&d), h.size() * sizeof(T)));
+  CK(hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  b.L.base = d;
+  CK(hipMalloc(reinterpret_cast<void**>(&b.partials), size_t(8192) * 28 * sizeof(double)));
+  CK(hipMalloc(reinterpret_cast<void**>(&b.counter), 4096));
+  CK(hipMemset(b.counter, 0, 4096));
+  CK(hipMalloc(reinterpret_cast<void**>(&b.out), 32 * sizeof(double)));
+  Ndt6Params<T> P{};
+  const double c = std::cos(0.02), s = std::sin(0.02);
+  const double R[9] = {c, -s, 0, s, c, 0, 0, 0, 1};
+  for (int k = 0; k < 9; ++k) P.R[k] = T(R[k]);
+  P.t[0] = T(0.01), P.t[1] = T(-0.02), P.t[2] = T(0.03);
+  P.la = T(1), P.lb = T(1), P.lc = T(2);
+  double ref[28] = {0};
+  printf("layout: %s\n", tile_log2 > 0 ? "tiles of 1024" : "planar + skew");
+#define RUNN(ITEMS, BLOCK, MINW, PF, BPC) \
+  run<PE, T, ITEMS, BLOCK, MINW, true, PF>(b, P, BPC, ref, "ndt6 nt items=" #ITEMS " block=" #BLOCK " minw=" #MINW " pf=" #PF " bpc=" #BPC)
+  if constexpr (sizeof(T) == 4) {
+    RUNN(2, 512, 2, 1, 1);
+    RUNN(2, 512, 2, 2, 1);
+    RUNN(2, 512, 2, 0, 1);
+    RUNN(2, 256, 2, 2, 2);
+    RUNN(1, 1024, 4, 1, 1);
+    RUNN(1, 1024, 4, 2, 1);
+    RUNN(2, 1024, 4, 1, 1);
+    if (tile_log2 <= 0) {
+      RUNN(4, 256, 2, 0, 1);
+      RUNN(4, 256, 2, 1, 1);
+      RUNN(4, 512, 2, 0, 1);
+      RUNN(4, 512, 2, 1, 1);
+    }
+  } else {
+    RUNN(1, 512, 3, 0, 1);
+    RUNN(1, 512, 2, 1, 1);
+    RUNN(2, 512, 2, 0, 1);
+  }
+#undef RUNN
+  {
+    using PS = StreamOnlyProblem<T, 15>;
+    typename PS::Params Q{};
+    double r2[28] = {0};
+    if constexpr (sizeof(T) == 4) {
+      run<PS, T, 2, 512, 2, true, 1>(b, Q, 1, r2, "stream-only nt items=2 block=512 pf=1");
+      double r3[28] = {0};
+      run<PS, T, 2, 512, 2, true, 2>(b, Q, 1, r3, "stream-only nt items=2 block=512 pf=2");
+    } else {
+      run<PS, T, 1, 512, 3, true, 0>(b, Q, 1, r2, "stream-only nt items=1 block=512");
+    }
+  }
+  CK(hipFree(d));
 }
 
 int main(int argc, char** argv) {
@@ -148,6 +266,13 @@ int main(int argc, char** argv) {
       bench_reproj<double>(n, prop.multiProcessorCount);
     else
       bench_reproj<float>(n, prop.multiProcessorCount);
+  } else if (what == "ndt6") {
+    if (dtype == "f64") {
+      bench_ndt6<double>(n, prop.multiProcessorCount, 0);
+    } else {
+      bench_ndt6<float>(n, prop.multiProcessorCount, 10);
+      bench_ndt6<float>(n, prop.multiProcessorCount, 0);
+    }
   }
   return 0;
 }
