@@ -511,8 +511,9 @@ def main():
         # are brought up, self-tested and timed for R trains of K steps, and both results are printed.
         # NOS_BENCH_COMM = rccl | mailbox | torch restricts the set.
         want = os.environ.get("NOS_BENCH_COMM", "both")
-        order = {"both": ["rccl-native", "mailbox"], "auto": ["rccl-native", "mailbox"], "rccl": ["rccl-native"],
-                 "mailbox": ["mailbox"], "torch": []}.get(want, ["rccl-native", "mailbox"])
+        order = {"both": ["rccl-native", "mailbox_device", "mailbox"], "auto": ["rccl-native", "mailbox_device", "mailbox"],
+                 "rccl": ["rccl-native"], "mailbox": ["mailbox"], "mailbox_device": ["mailbox_device"],
+                 "torch": []}.get(want, ["rccl-native", "mailbox_device", "mailbox"])
         if shared_gpu:
             order = [c for c in order if c != "rccl-native"]  # RCCL refuses two ranks on one device
 
@@ -522,6 +523,8 @@ def main():
                 with _StdoutToStderr():
                     if candidate == "mailbox":
                         ctx.comm_init_shm_from_torch()
+                    elif candidate == "mailbox_device":
+                        ctx.comm_init_shm_from_torch(device_memory=True)
                     else:
                         ctx.comm_init_from_torch()
                         seen = ctx.comm_rccl_count
@@ -538,7 +541,8 @@ def main():
             vote = torch.tensor([ok, -micros], dtype=torch.float64)
             dist.all_reduce(vote, op=dist.ReduceOp.MIN)  # all ranks ok, and the slowest rank's time
             if float(vote[0].item()) > 0.5:
-                return {"allreduce_call_us": -float(vote[1].item()), "ranks_seen": seen if candidate != "mailbox" else ctx.comm_size}
+                return {"allreduce_call_us": -float(vote[1].item()),
+                        "ranks_seen": seen if not candidate.startswith("mailbox") else ctx.comm_size}
             if ctx.comm_size > 0:
                 ctx.comm_destroy()
             return None
@@ -548,13 +552,15 @@ def main():
             if up is None:
                 continue
             it = (lambda k: work.iterate_device(ds, k)) if args.loop == "device" else (lambda k: work.iterate_host(ds, k))
-            legs[candidate] = run_trains(it, bracket=(candidate == "mailbox" and args.loop == "device"))
+            legs[candidate] = run_trains(it, bracket=(candidate.startswith("mailbox") and args.loop == "device"))
             legs[candidate].update(up)
             if candidate == "rccl-native":
                 legs[candidate]["ncclCommCount"] = up["ranks_seen"]
             ctx.comm_destroy()
         if "rccl-native" in legs:
             comm_mode = "rccl-native"
+        elif "mailbox_device" in legs:
+            comm_mode = "mailbox_device"
         elif "mailbox" in legs:
             comm_mode = "mailbox"
         else:
@@ -592,7 +598,7 @@ def main():
     k_med = kern["median"] if kern else 0.0
     achieved = bytes_per_launch / (k_med * 1e-3) / 1e9 if k_med > 0 else 0.0
     device_loop = args.loop == "device" and comm_mode != "torch.distributed(gloo)"
-    bracket = dist is None and args.loop == "device" or (comm_mode == "mailbox" and args.loop == "device")
+    bracket = dist is None and args.loop == "device" or (comm_mode.startswith("mailbox") and args.loop == "device")
 
     # ---- second placement of the loop at N = 1 (host loop beside the device loop), one train
     host_loop = None
@@ -745,7 +751,7 @@ def main():
             "step": ("LM iteration, device resident: pass over the data + grid-wide reduce%s + LDLT / pose update / "
                      "lambda schedule on the GPU (one launch for the whole loop when launches_per_train = 1, else one per "
                      "iteration with the next launch already queued)"
-                     % ("" if world == 1 else (" + in-launch mailbox all-reduce" if comm_mode == "mailbox"
+                     % ("" if world == 1 else (" + in-launch mailbox all-reduce" if comm_mode.startswith("mailbox")
                                                else " + RCCL all-reduce(28 f64) + step kernel")))
                     if device_loop else
                     ("LM iteration: assemble kernel + final reduce%s + readback + host LDLT / pose update"

@@ -128,6 +128,13 @@ int nos_runtime_info(char* buf, size_t capacity);
  * (MDM/..._analytic_simd.cc:70-75) across processes.  At most 64 ranks; all ranks must issue the same sequence of
  * calls; a rank that never arrives makes the others return NOS_ERR_HIP after 8 s instead of hanging. */
 int nos_ctx_comm_init_shm(nos_ctx* ctx, int n_ranks, int rank, const char* shm_name);
+/* The same communicator with its SLOTS in device memory: every rank allocates its slot buffer as fine-grained device
+ * memory, exports it with hipIpcGetMemHandle through the shared-memory segment (which keeps the handshake and control
+ * words only) and opens the buffers of its peers; inside the launch a rank then writes its 28 sums and its round number
+ * straight into every peer's buffer — device to device, over xGMI between GPUs — and polls only its own memory.  Same
+ * slots, same round numbers, same rank-order sum: bit-identical to the host-memory form.  NOS_ERR_UNSUPPORTED when the
+ * platform refuses the fine-grained allocation or the IPC export / import. */
+int nos_ctx_comm_init_shm_device(nos_ctx* ctx, int n_ranks, int rank, const char* shm_name);
 int nos_comm_shm_unlink(const char* shm_name);
 /* Leaves whichever communicator the context has (collective for RCCL); nos_ctx_destroy does it implicitly. */
 int nos_ctx_comm_destroy(nos_ctx* ctx);

@@ -25,7 +25,7 @@ NOS_LOSS_HUBER = 2
 # every symbol include/nos.h declares; tests check the library exports all of them
 C_ABI_SYMBOLS = (
     "nos_ctx_create", "nos_ctx_destroy", "nos_ctx_num_devices", "nos_ctx_set_stream",
-    "nos_ctx_synchronize", "nos_comm_get_unique_id", "nos_ctx_comm_init", "nos_ctx_comm_size", "nos_ctx_comm_init_shm", "nos_comm_shm_unlink", "nos_ctx_comm_destroy",
+    "nos_ctx_synchronize", "nos_comm_get_unique_id", "nos_ctx_comm_init", "nos_ctx_comm_size", "nos_ctx_comm_init_shm", "nos_ctx_comm_init_shm_device", "nos_comm_shm_unlink", "nos_ctx_comm_destroy",
     "nos_ctx_comm_allreduce", "nos_ndt_dataset_create", "nos_reproj_dataset_create",
     "nos_ndt_dataset_create_from_device", "nos_reproj_dataset_create_from_device",
     "nos_ndt_dataset_create_from_records", "nos_reproj_dataset_create_from_records",
@@ -103,6 +103,8 @@ def _declare(lib):
     lib.nos_comm_get_unique_id.argtypes = [ctypes.c_char_p]
     lib.nos_ctx_comm_init.argtypes = [vp, i, i, ctypes.c_char_p]
     lib.nos_ctx_comm_init_shm.argtypes = [vp, i, i, ctypes.c_char_p]
+    if hasattr(lib, "nos_ctx_comm_init_shm_device"):
+        lib.nos_ctx_comm_init_shm_device.argtypes = [vp, i, i, ctypes.c_char_p]
     lib.nos_comm_shm_unlink.argtypes = [ctypes.c_char_p]
     lib.nos_ctx_comm_destroy.argtypes = [vp]
     lib.nos_ctx_comm_size.argtypes = [vp]

@@ -139,12 +139,17 @@ class Context:
         dist.broadcast_object_list(payload, src=0, group=group)
         self.comm_init(world, rank, payload[0])
 
-    def comm_init_shm(self, n_ranks, rank, name):
-        """Collective (ranks of one node): join the shared-memory mailbox communicator `name` ('/...'); the sums are
-        then exchanged inside the launch (nos_ctx_comm_init_shm)."""
-        check(self._lib.nos_ctx_comm_init_shm(self._h, n_ranks, rank, name.encode()), "nos_ctx_comm_init_shm")
+    def comm_init_shm(self, n_ranks, rank, name, device_memory=False):
+        """Collective (ranks of one node): join the mailbox communicator `name` ('/...'); the sums are then exchanged
+        inside the launch.  device_memory=False: slots in the POSIX shared-memory segment (nos_ctx_comm_init_shm);
+        True: slots in fine-grained device memory of every rank, shared through HIP IPC handles — peers write into each
+        other's buffers device to device (nos_ctx_comm_init_shm_device)."""
+        if device_memory:
+            check(self._lib.nos_ctx_comm_init_shm_device(self._h, n_ranks, rank, name.encode()), "nos_ctx_comm_init_shm_device")
+        else:
+            check(self._lib.nos_ctx_comm_init_shm(self._h, n_ranks, rank, name.encode()), "nos_ctx_comm_init_shm")
 
-    def comm_init_shm_from_torch(self, group=None):
+    def comm_init_shm_from_torch(self, group=None, device_memory=False):
         """Bootstrap the mailbox communicator through an initialised torch.distributed group: rank 0 picks a fresh
         name, every rank attaches, rank 0 unlinks the name once all are in (the mapping stays alive)."""
         import torch.distributed as dist
@@ -153,7 +158,7 @@ class Context:
         payload = ["/nos_%s" % uuid.uuid4().hex if rank == 0 else None]
         dist.broadcast_object_list(payload, src=0, group=group)
         try:
-            self.comm_init_shm(world, rank, payload[0])
+            self.comm_init_shm(world, rank, payload[0], device_memory=device_memory)
         finally:
             dist.barrier(group=group)
             if rank == 0:

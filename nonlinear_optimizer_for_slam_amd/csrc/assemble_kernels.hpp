@@ -849,6 +849,8 @@ constexpr int kMailSlotDoubles = 64;                         // one slot: [0..27
 constexpr unsigned long long kMailboxTimeoutTicks = 800000000ull;  // 8 s
 struct Mailbox {
   double* base;                 // device address of the shared mailbox: [n_ranks][2][kMailSlotDoubles]; null = no exchange
+  double* const* peers;         // device-memory form: peers[r] = rank r's [n_ranks][2][kMailSlotDoubles] buffer (fine-grained
+                                // device memory, peers[rank] is local); null = the slots behind `base` (host memory)
   unsigned long long* round;    // device word: rounds completed by this rank (all ranks run the same sequence)
   unsigned int* error_host;     // host-mapped word set to 1 when a peer did not arrive in time
   int n_ranks;
@@ -887,14 +889,30 @@ __device__ __forceinline__ double mailbox_allreduce(const Mailbox& mb, double to
 #ifdef NOS_LM_TIMING
   unsigned long long tm0 = wall_clock64(), tm1 = 0, tm2 = 0;
 #endif
-  double* mine = mb.base + (size_t(mb.rank) * 2 + parity) * kMailSlotDoubles;
-  if (threadIdx.x < NOUT) __hip_atomic_store(mine + threadIdx.x, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  // Host-memory form: every rank stores into ITS slot of the one shared segment and polls the others' slots there.
+  // Device-memory form: every rank PUSHES its slot into every peer's buffer (remote stores over the fabric; its own buffer
+  // included) and polls only its own, local memory — the same slots, the same round numbers, the same rank-order sum.
+  const size_t my_slot = (size_t(mb.rank) * 2 + parity) * kMailSlotDoubles;
+  const bool pushed = mb.peers != nullptr;
+  double* const local = pushed ? mb.peers[mb.rank] : mb.base;  // where this rank polls and sums
+  if (threadIdx.x < NOUT) {
+    if (pushed) {
+      for (int p = 0; p < mb.n_ranks; ++p)
+        __hip_atomic_store(mb.peers[p] + my_slot + threadIdx.x, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else {
+      __hip_atomic_store(mb.base + my_slot + threadIdx.x, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
   if (threadIdx.x < kWave) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the sums left through lanes of wave 0
-    if (threadIdx.x == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(reinterpret_cast<unsigned long long*>(mine + 32), round, __ATOMIC_RELAXED,
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (pushed) {
+      if (int(threadIdx.x) < mb.n_ranks)  // lane p raises this rank's flag in peer p's buffer
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(mb.peers[threadIdx.x] + my_slot + 32), round, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    } else if (threadIdx.x == 0) {
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(mb.base + my_slot + 32), round, __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_SYSTEM);
     }
 #ifdef NOS_LM_TIMING
@@ -902,7 +920,7 @@ __device__ __forceinline__ double mailbox_allreduce(const Mailbox& mb, double to
 #endif
     if (int(threadIdx.x) < mb.n_ranks) {
       const unsigned long long* flag = reinterpret_cast<const unsigned long long*>(
-          mb.base + (size_t(threadIdx.x) * 2 + parity) * kMailSlotDoubles + 32);
+          local + (size_t(threadIdx.x) * 2 + parity) * kMailSlotDoubles + 32);
       const unsigned long long deadline = wall_clock64() + kMailboxTimeoutTicks;
       while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != round) {
         if (wall_clock64() > deadline) {  // a peer is missing: report, do not hang
@@ -924,7 +942,7 @@ __device__ __forceinline__ double mailbox_allreduce(const Mailbox& mb, double to
   double sum = 0.0;
   if (threadIdx.x < NOUT) {
     for (int r = 0; r < mb.n_ranks; ++r)  // rank order: the same additions on every rank
-      sum += __hip_atomic_load(mb.base + (size_t(r) * 2 + parity) * kMailSlotDoubles + threadIdx.x, __ATOMIC_RELAXED,
+      sum += __hip_atomic_load(local + (size_t(r) * 2 + parity) * kMailSlotDoubles + threadIdx.x, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_SYSTEM);
   }
   if (threadIdx.x == 0) *mb.round = round;

@@ -508,6 +508,7 @@ nos::Mailbox mailbox_of(const nos_ctx* ctx, const DeviceSlot& slot) {
   nos::Mailbox mb{};
   if (ctx->shm_dev == nullptr) return mb;
   mb.base = ctx->shm_dev;
+  mb.peers = ctx->d_peers;  // null: the slots are the host-memory ones behind `base`
   mb.round = ctx->d_round;
   mb.error_host = reinterpret_cast<unsigned int*>(slot.h_out_dev + kCommErrorSlot);
   mb.n_ranks = ctx->comm_ranks;
@@ -1474,6 +1475,13 @@ int nos_ctx_comm_destroy(nos_ctx* ctx) {
       (void)hipSetDevice(ctx->slots[0].device);
       (void)hipStreamSynchronize(ctx->slots[0].stream);
     }
+    for (size_t k = 0; k < ctx->ipc_peers.size(); ++k)
+      if (ctx->ipc_peers[k] != nullptr && int(k) != ctx->comm_rank) (void)hipIpcCloseMemHandle(ctx->ipc_peers[k]);
+    ctx->ipc_peers.clear();
+    if (ctx->ipc_own) (void)hipFree(ctx->ipc_own);
+    if (ctx->d_peers) (void)hipFree(ctx->d_peers);
+    ctx->ipc_own = nullptr;
+    ctx->d_peers = nullptr;
     (void)hipHostUnregister(ctx->shm_host);
     munmap(ctx->shm_host, ctx->shm_bytes);
     if (ctx->d_round) (void)hipFree(ctx->d_round);
@@ -1903,7 +1911,14 @@ int nos_ctx_comm_init(nos_ctx* ctx, int n_ranks, int rank, const unsigned char i
 
 int nos_ctx_comm_size(const nos_ctx* ctx) { return (ctx && (ctx->comm || ctx->shm_dev)) ? ctx->comm_ranks : 0; }
 
-int nos_ctx_comm_init_shm(nos_ctx* ctx, int n_ranks, int rank, const char* shm_name) {
+}  // extern "C"
+
+namespace {
+// Both mailbox communicators: the handshake and control words always live in the POSIX shm segment; the SLOTS the kernels
+// exchange through live there too (device_slots = false: bytes travel over PCIe to host memory) or in fine-grained device
+// memory of every rank, exported with hipIpcGetMemHandle and opened by the peers (device_slots = true: a rank writes its
+// sums straight into every peer's buffer — over xGMI between GPUs — and polls only its own memory).
+int comm_init_mailbox(nos_ctx* ctx, int n_ranks, int rank, const char* shm_name, bool device_slots) {
   nosd::CtxGuard guard_(ctx);  // one solve / accumulate / create at a time per context
   if (!ctx || !shm_name || shm_name[0] != '/' || n_ranks < 1 || n_ranks > 64 || rank < 0 || rank >= n_ranks)
     return fail(NOS_ERR_INVALID_ARGUMENT, "bad comm arguments (name must start with '/', at most 64 ranks)");
@@ -1921,7 +1936,9 @@ int nos_ctx_comm_init_shm(nos_ctx* ctx, int n_ranks, int rank, const char* shm_n
   // Bounded: NOS_SHM_ATTACH_TIMEOUT_MS (default 30 s) in total.  Header (after the slots): [0] nonce, [1..64] hello, [65..128] ack.
   const int kAttachTimeoutMs = std::max(100, env_int("NOS_SHM_ATTACH_TIMEOUT_MS", 30000));  // set-up path, not the solve path
   const size_t slots_bytes = size_t(n_ranks) * 2 * nos::kMailSlotDoubles * sizeof(double);
-  const size_t header_words = 1 + 64 + 64;
+  // header (after the slots), in 8-byte words: [0] nonce, [1..64] hello, [65..128] ack, [129..192] ipc-ready, [193..704] 64 IPC handles of 64 bytes
+  const size_t header_words = 1 + 64 + 64 + 64 + 64 * 8;
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
   bytes = (slots_bytes + header_words * sizeof(unsigned long long) + 4095) & ~size_t(4095);
   auto now_ms = [] {
     return std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -2027,6 +2044,63 @@ int nos_ctx_comm_init_shm(nos_ctx* ctx, int n_ranks, int rank, const char* shm_n
   ctx->d_round = d_round;
   ctx->comm_ranks = n_ranks;
   ctx->comm_rank = rank;
+  if (device_slots) {
+    // every rank: its own [n_ranks][2][kMailSlotDoubles] buffer in fine-grained device memory (peers write into it across the
+    // fabric while this GPU polls it: no cache may keep a stale copy), exported through the shm header and opened by the others
+    auto* hdr = reinterpret_cast<std::atomic<unsigned long long>*>(static_cast<char*>(host) + slots_bytes);
+    hipIpcMemHandle_t* handles = reinterpret_cast<hipIpcMemHandle_t*>(hdr + 193);
+    double* own = nullptr;
+    e = hipExtMallocWithFlags(reinterpret_cast<void**>(&own), slots_bytes, hipDeviceMallocFinegrained);
+    if (e == hipSuccess) e = hipMemset(own, 0, slots_bytes);
+    hipIpcMemHandle_t mine{};
+    if (e == hipSuccess) e = hipIpcGetMemHandle(&mine, own);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+      if (own) (void)hipFree(own);
+      (void)nos_ctx_comm_destroy(ctx);
+      return fail(NOS_ERR_UNSUPPORTED, "device-memory mailbox: fine-grained allocation / IPC export failed: %s", hipGetErrorString(e));
+    }
+    ctx->ipc_own = own;
+    memcpy(&handles[rank], &mine, sizeof mine);
+    hdr[129 + rank].store(1ull, std::memory_order_release);
+    ctx->ipc_peers.assign(size_t(n_ranks), nullptr);
+    ctx->ipc_peers[size_t(rank)] = own;
+    for (int k = 0; k < n_ranks; ++k) {
+      if (k == rank) continue;
+      while (hdr[129 + k].load(std::memory_order_acquire) == 0ull) {
+        if (now_ms() > deadline) {
+          (void)nos_ctx_comm_destroy(ctx);
+          return fail(NOS_ERR_HIP, "device-memory mailbox %s: rank %d did not publish its IPC handle within %d ms", shm_name, k, kAttachTimeoutMs);
+        }
+        usleep(200);
+      }
+      hipIpcMemHandle_t theirs;
+      memcpy(&theirs, &handles[k], sizeof theirs);
+      void* p = nullptr;
+      e = hipIpcOpenMemHandle(&p, theirs, hipIpcMemLazyEnablePeerAccess);
+      if (e != hipSuccess) {
+        (void)nos_ctx_comm_destroy(ctx);
+        return fail(NOS_ERR_UNSUPPORTED, "device-memory mailbox: hipIpcOpenMemHandle(rank %d) failed: %s", k, hipGetErrorString(e));
+      }
+      ctx->ipc_peers[size_t(k)] = static_cast<double*>(p);
+    }
+    e = hipMalloc(reinterpret_cast<void**>(&ctx->d_peers), sizeof(double*) * size_t(n_ranks));
+    if (e == hipSuccess) e = hipMemcpy(ctx->d_peers, ctx->ipc_peers.data(), sizeof(double*) * size_t(n_ranks), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+      (void)nos_ctx_comm_destroy(ctx);
+      return fail(NOS_ERR_HIP, "device-memory mailbox: uploading the peer table failed: %s", hipGetErrorString(e));
+    }
+    // nobody may start exchanging (or leave and free its buffer) before every rank has opened every buffer
+    hdr[129 + rank].store(2ull, std::memory_order_release);
+    for (int k = 0; k < n_ranks; ++k)
+      while (hdr[129 + k].load(std::memory_order_acquire) < 2ull) {
+        if (now_ms() > deadline) {
+          (void)nos_ctx_comm_destroy(ctx);
+          return fail(NOS_ERR_HIP, "device-memory mailbox %s: rank %d did not finish attaching within %d ms", shm_name, k, kAttachTimeoutMs);
+        }
+        usleep(200);
+      }
+  }
   const nos::Mailbox mb = mailbox_of(ctx, slot);
   e = hipMalloc(reinterpret_cast<void**>(&ctx->d_mail), sizeof(nos::Mailbox));
   if (e == hipSuccess) e = hipMemcpy(ctx->d_mail, &mb, sizeof mb, hipMemcpyHostToDevice);
@@ -2035,6 +2109,18 @@ int nos_ctx_comm_init_shm(nos_ctx* ctx, int n_ranks, int rank, const char* shm_n
     return fail(NOS_ERR_HIP, "uploading the mailbox descriptor failed: %s", hipGetErrorString(e));
   }
   return NOS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nos_ctx_comm_init_shm(nos_ctx* ctx, int n_ranks, int rank, const char* shm_name) {
+  return comm_init_mailbox(ctx, n_ranks, rank, shm_name, false);
+}
+
+int nos_ctx_comm_init_shm_device(nos_ctx* ctx, int n_ranks, int rank, const char* shm_name) {
+  return comm_init_mailbox(ctx, n_ranks, rank, shm_name, true);
 }
 
 int nos_comm_shm_unlink(const char* shm_name) {

@@ -174,6 +174,10 @@ struct nos_ctx {
   double* shm_dev = nullptr;           // its device address (hipHostRegister, mapped)
   unsigned long long* d_round = nullptr;  // device word: exchange rounds completed
   nos::Mailbox* d_mail = nullptr;         // device copy of the descriptor the kernels read
+  // device-memory mailbox (nos_ctx_comm_init_shm_device): every rank's slot buffer, fine-grained device memory
+  double* ipc_own = nullptr;              // this rank's buffer
+  std::vector<double*> ipc_peers;         // [rank] → that rank's buffer as mapped here (own buffer at comm_rank)
+  double** d_peers = nullptr;             // device copy of ipc_peers
 };
 
 namespace nosd {

@@ -104,7 +104,7 @@ def test_two_processes_sharing_one_gpu_match_the_single_process_solve(tmp_path):
 
 # ------------------------------------------------------------------ in-launch mailbox all-reduce (nos_ctx_comm_init_shm)
 
-def _mailbox_worker(rank, world, name, n, out_dir):
+def _mailbox_worker(rank, world, name, n, out_dir, device_memory=False):
     """One process per rank, all on GPU 0 (a one-GPU box): shard of the correspondences, mailbox communicator,
     one accumulate and one device-resident solve.  No torch, no RCCL: the exchange happens inside the launches."""
     import numpy as np
@@ -113,7 +113,7 @@ def _mailbox_worker(rank, world, name, n, out_dir):
     planes = synth.ndt_planes(n, 2000)
     lo, hi = distributed.shard_range(n, rank, world)
     ctx = Context((0,))
-    ctx.comm_init_shm(world, rank, name)
+    ctx.comm_init_shm(world, rank, name, device_memory=device_memory)
     assert ctx.comm_size == world
     ds = NdtDataset.from_planes(ctx, np.ascontiguousarray(planes[:, lo:hi]), "f64")
     probe = ctx.comm_allreduce([rank + 1.0, 1.0])
@@ -129,20 +129,34 @@ def _mailbox_worker(rank, world, name, n, out_dir):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("device_memory", [False, True])
 @pytest.mark.parametrize("world", [2, 3])
-def test_mailbox_allreduce_ranks_agree_bitwise_and_match_one_process(tmp_path, world):
+def test_mailbox_allreduce_ranks_agree_bitwise_and_match_one_process(tmp_path, world, device_memory):
     """SURVEY §8e with the exchange inside the launch: W processes (sharing GPU 0 here), each owning a contiguous shard;
-    every rank must end with identical bits, equal to the single-process result up to summation order."""
+    every rank must end with identical bits, equal to the single-process result up to summation order.  device_memory:
+    the slots live in fine-grained device memory shared through HIP IPC handles (peers push into each other's buffers)
+    instead of the host shared-memory segment — and must give the SAME bits as the host-memory form."""
     import uuid
     from nonlinear_optimizer_for_slam_amd import Context, NdtDataset, api, synth
     from tests import helpers
     n = 90_001
     name = "/nos_test_%s" % uuid.uuid4().hex
     try:
-        mp.spawn(_mailbox_worker, args=(world, name, n, str(tmp_path)), nprocs=world, join=True)
+        mp.spawn(_mailbox_worker, args=(world, name, n, str(tmp_path), device_memory), nprocs=world, join=True)
     finally:
         api.shm_unlink(name)
     ranks = [np.load(tmp_path / ("mail_rank%d.npz" % r)) for r in range(world)]
+    if device_memory:  # bit for bit what the host-memory transport gives
+        host_dir = tmp_path / "host_form"
+        host_dir.mkdir()
+        name2 = "/nos_test_%s" % uuid.uuid4().hex
+        try:
+            mp.spawn(_mailbox_worker, args=(world, name2, n, str(host_dir), False), nprocs=world, join=True)
+        finally:
+            api.shm_unlink(name2)
+        ref = np.load(host_dir / "mail_rank0.npz")
+        for key in ("out", "R", "t", "cost", "R2", "t2"):
+            assert np.array_equal(ranks[0][key], ref[key]), key
     for r in ranks:
         assert int(r["ok"]) == 1
         np.testing.assert_array_equal(r["probe"], [world * (world + 1) / 2.0, float(world)])

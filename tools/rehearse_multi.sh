@@ -12,6 +12,7 @@ python - <<'PY'
 import json
 for f in ("rehearse_n1_forced", "rehearse_n2", "rehearse_n4"):
     r = json.loads(open("gpurun_out/%s.json" % f).read().strip().splitlines()[-1])
-    print("%-20s n_gpus %d collective %-12s loop %-6s step %.4f ms  value %.2f G corr/s  err %.2e" % (
-        f, r["n_gpus"], r["config"]["collective"], r["config"]["loop"], r["ms_per_step"], r["value"] / 1e9, r["final_translation_error_m"]))
+    print("%-20s n_gpus %d collective %-14s loop %-6s step %.4f ms  value %.2f G corr/s  err %.2e   timed: %s" % (
+        f, r["n_gpus"], r["config"]["collective"], r["config"]["loop"], r["ms_per_step"], r["value"] / 1e9, r["final_translation_error_m"],
+        {k: round(v["ms_per_step"]["median"], 4) for k, v in r["config"]["collectives_timed"].items()}))
 PY
