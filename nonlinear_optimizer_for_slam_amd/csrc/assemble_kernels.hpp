@@ -1413,7 +1413,47 @@ __global__ __launch_bounds__(BLOCK, MINW) void assemble_kernel(TiledLayout L,
     i0 = uint64_t(c) * kChunk + uint64_t(threadIdx.x) * ITEMS;
     return (i0 >> L.tile_shift) * L.tile_stride + (i0 & L.tile_mask);
   };
-  if constexpr (PREFETCH == 2) {
+  if constexpr (PREFETCH == 3) {
+    // ping-pong: two named buffers, the loop unrolled twice — while buffer A is evaluated the loads into B are in flight and
+    // vice versa.  No register copies and NO branch around a load in the steady state (the tail is peeled), so the wait
+    // before an evaluation is a counted one for the OLDER group of loads only: a wave always has a chunk in flight.
+    T xa[kF][ITEMS], xb[kF][ITEMS];
+    uint32_t c = blockIdx.x;
+    const uint32_t G = gridDim.x;
+    uint64_t ia = 0, ib = 0;
+    auto issue = [&](uint32_t cc, T (&dst)[kF][ITEMS], uint64_t& i0) {
+      const uint64_t off = chunk_offset(cc, i0);
+#pragma unroll
+      for (int f = 0; f < kF; ++f) load_items<T, ITEMS, NT>(base + off + uint64_t(f) * L.field_stride, dst[f]);
+    };
+    auto evaluate = [&](const T (&src)[kF][ITEMS], uint64_t i0) {
+#pragma unroll
+      for (int it = 0; it < ITEMS; ++it) {
+        T xi[kF];
+#pragma unroll
+        for (int f = 0; f < kF; ++f) xi[f] = src[f][it];
+        Problem::item(xi, P, (i0 + it) < L.n, acc);
+      }
+    };
+    const bool any = c < n_chunks;  // block-uniform
+    if (any) issue(c, xa, ia);
+    if (lm_prologue(fin, P)) return;  // grid-uniform
+    if (any) {
+      while (uint64_t(c) + 2ull * G < n_chunks) {
+        issue(c + G, xb, ib);
+        __builtin_amdgcn_sched_barrier(0);
+        evaluate(xa, ia);
+        issue(c + 2 * G, xa, ia);
+        __builtin_amdgcn_sched_barrier(0);
+        evaluate(xb, ib);
+        c += 2 * G;
+      }
+      const bool has_b = uint64_t(c) + G < n_chunks;  // block-uniform
+      if (has_b) issue(c + G, xb, ib);
+      evaluate(xa, ia);
+      if (has_b) evaluate(xb, ib);
+    }
+  } else if constexpr (PREFETCH == 2) {
     // two chunks ahead: while chunk c is evaluated the loads of c + G and c + 2G are in flight
     T xa[kF][ITEMS], xb[kF][ITEMS];
     uint32_t c = blockIdx.x;

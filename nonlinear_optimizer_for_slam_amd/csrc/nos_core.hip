@@ -130,13 +130,13 @@ size_t layout_elems(const nos::TiledLayout& L, int n_fields) {
 
 // Number of compiled geometry variants per dtype (see the NOS_CASE tables below; index 0
 // is the default).
-constexpr int kNumVariants = 11;
+constexpr int kNumVariants = 14;
 
 // Host function of the hot-path kernel the current thread launched last (launch_variant / launch_single); copied into
 // the device slot by launch_assemble_raw so that nos_ctx_last_kernel can name the instantiation that actually ran.
 thread_local const void* t_last_kernel = nullptr;
 
-template <typename Problem, typename T, int ITEMS, int BLOCK, int MINW, bool PREFETCH = false>
+template <typename Problem, typename T, int ITEMS, int BLOCK, int MINW, int PREFETCH = 0>
 int launch_variant(const nos::TiledLayout& L, const typename Problem::Params& P, int grid_cap, int num_cus_hint,
                    bool nt, double* partials, const nos::FusedFinal& fin_in, hipStream_t stream, int* rows_out) {
   constexpr uint32_t kChunk = BLOCK * ITEMS;
@@ -176,51 +176,65 @@ int launch_by_variant(int variant, int blocks_per_cu, int num_cus, const nos::Ti
 #define NOS_CASE_PF(idx, ITEMS_, BLOCK_, MINW_, BPC_)                                               \
   case idx: {                                                                                       \
     const int bpc = blocks_per_cu > 0 ? blocks_per_cu : BPC_;                                       \
-    return launch_variant<Problem, T, ITEMS_, BLOCK_, MINW_, true>(L, P, bpc * num_cus, num_cus, nt, partials, fin, \
-                                                                   stream, rows_out);               \
+    return launch_variant<Problem, T, ITEMS_, BLOCK_, MINW_, 1>(L, P, bpc * num_cus, num_cus, nt, partials, fin, \
+                                                                stream, rows_out);                  \
   }
-  // The default build carries the geometries something selects by default or a test drives (fp64 0, 1, 3; fp32 0, 1, 8);
-  // the others lost every measurement (profiles/r01_tune_*.txt, r02_tune_f32*.txt), several of them spill, and together
-  // they were two thirds of the 430 kernels of this translation unit.  `make ALL_VARIANTS=1` (-DNOS_ALL_VARIANTS) compiles
-  // them all again for tools/tune_*.py and the geometry test.
+#define NOS_CASE_PP(idx, ITEMS_, BLOCK_, MINW_, BPC_)                                               \
+  case idx: {                                                                                       \
+    const int bpc = blocks_per_cu > 0 ? blocks_per_cu : BPC_;                                       \
+    return launch_variant<Problem, T, ITEMS_, BLOCK_, MINW_, 3>(L, P, bpc * num_cus, num_cus, nt, partials, fin, \
+                                                                stream, rows_out);                  \
+  }
+  // variant 0 = the library's choice for this problem / element type / layout (round 3, tools/exp/tune_stream.hip on
+  // MI355X, profiles/r03_tune_*.txt):
+  //   reprojection (5 planes: a chunk is only 40 B / 20 B per lane, so what a wave keeps in flight decides) — the ping-pong
+  //     form, two named buffers and counted waits: fp64 21.3 -> 17.5 us per launch at 2 M, fp32 16.7 -> 14.5 us;
+  //   NDT fp32 — 8-byte loads of two items, two waves per SIMD, no software prefetch: 89.0 us per launch at 10 M against
+  //     100.5 us of round 2's prefetched form (its register copies forced full waits) and a loads-only floor of 89.8 us;
+  //   NDT fp64 — one item per lane, 512-thread blocks (unchanged).
+  // The default build carries the geometries something selects by default or a test drives; `make ALL_VARIANTS=1`
+  // (-DNOS_ALL_VARIANTS) compiles every geometry ever tried for tools/tune_*.py and the geometry sweep test.
+  constexpr bool kReproj = Problem::kFields == 5;
   if constexpr (sizeof(T) == 8) {
+    if (variant == 0 && kReproj) variant = 7;
     switch (variant) {
       NOS_CASE(0, 1, 512, 3, 1)
       NOS_CASE(1, 1, 256, 3, 2)
       NOS_CASE(3, 2, 256, 2, 2)
+      NOS_CASE_PP(7, 1, 512, kReproj ? 3 : 2, 1)   // ping-pong, one item per lane (two 15-plane buffers need the 256-register budget)
 #ifdef NOS_ALL_VARIANTS
       NOS_CASE(2, 1, 256, 2, 2)
       NOS_CASE(4, 2, 512, 2, 1)
       NOS_CASE_PF(5, 1, 512, 2, 1)
       NOS_CASE_PF(6, 1, 256, 2, 2)
+      NOS_CASE_PP(8, 2, 512, 2, 1)
 #endif
     }
   } else {
-    if (variant == 0 && L.tile_stride != 0) variant = 8;  // the default follows the layout (see kDefaultTileLog2F32)
+    if (variant == 0) variant = kReproj ? 11 : 1;
     switch (variant) {
-      // fp32 item math keeps a SIMD's VALU busy 52 % of a wave's lifetime at ONE wave per SIMD (PMC,
-      // profiles/r02_bench_ndt6_f32_summary.json).  Four waves per SIMD (variant 5) overlap loads and math better inside one
-      // launch (0.0981 → 0.0968 ms fused, profiles/r02_tune_f32.txt) but lose it again in the back-to-back device loop
-      // (0.1030 against 0.1011 ms per LM iteration), so the 16-byte-load form stays the default.
-      NOS_CASE(0, 4, 256, 2, 1)      // default on planar planes: 16-byte loads, one wave per SIMD
-      NOS_CASE(1, 2, 512, 2, 1)  // the fp64 default's shape: 8-byte loads, two waves per SIMD
-      NOS_CASE_PF(8, 2, 512, 2, 1)   // default on the tiled layout
+      NOS_CASE(1, 2, 512, 2, 1)      // 8-byte loads of two items, two waves per SIMD
+      NOS_CASE_PF(8, 2, 512, 2, 1)   // round 2's default on the tiled layout: the next chunk prefetched through register copies
+      NOS_CASE_PP(11, 2, 512, 2, 1)  // ping-pong
 #ifdef NOS_ALL_VARIANTS
       NOS_CASE(2, 1, 256, 4, 2)
       NOS_CASE(3, 2, 256, 5, 2)
       NOS_CASE(4, 2, 256, 4, 2)
       NOS_CASE(5, 1, 1024, 4, 1)  // four waves per SIMD, 4-byte loads
       NOS_CASE(6, 2, 1024, 4, 1)  // four waves per SIMD, 8-byte loads
-      NOS_CASE_PF(7, 4, 256, 2, 1)   // the default's shape, next chunk's loads in flight during the item math
+      NOS_CASE_PF(7, 4, 256, 2, 1)
       NOS_CASE(9, 2, 256, 3, 3)      // three waves per SIMD from three small workgroups per CU
       NOS_CASE_PF(10, 2, 256, 3, 3)
+      NOS_CASE_PP(12, 4, 512, 2, 1)
+      NOS_CASE(13, 4, 256, 2, 1)     // round 1's default on planar planes: 16-byte loads, one wave per SIMD
 #endif
     }
   }
 #undef NOS_CASE
 #undef NOS_CASE_PF
+#undef NOS_CASE_PP
   return fail(NOS_ERR_UNSUPPORTED, "launch geometry %d is not compiled into this build for this element type "
-              "(default build: fp64 0, 1, 3; fp32 0, 1, 8; `make ALL_VARIANTS=1` builds all)", variant);
+              "(default build: fp64 0, 1, 3, 7; fp32 1, 8, 11; `make ALL_VARIANTS=1` builds all)", variant);
 }
 
 // Correspondences a lane of the resident one-launch solve can hold (registers + LDS), by plane count and element type.
@@ -260,7 +274,10 @@ int launch_single(const nos::TiledLayout& L, const typename Problem::Params& P, 
   if (a.cluster_blocks > 0 && a.stream_chunks > 0) {
     // the whole loop in one launch, the data streamed from HBM every iteration (solve_cluster_kernel, SI > 0)
     constexpr int kSI = sizeof(T) == 8 ? 1 : 2;        // fp64: 8-byte loads of one item; fp32: 8-byte loads of two
-    constexpr bool kSPF = sizeof(T) == 4;              // fp32: next chunk prefetched (the geometry of launch variant 8)
+    // fp32 prefetched the next chunk through register copies in round 2 (the geometry of launch variant 8); the copies
+    // force full waits, and with the LM step out of the kernel the plain form is the faster one (tools/exp/tune_stream.hip:
+    // 89.0 against 100.5 us per pass at 10 M; loads-only floor 89.8)
+    constexpr bool kSPF = false;
     constexpr size_t kChunk = size_t(kBlock) * kSI;
     if (L.n_padded % kChunk != 0 || (L.tile_stride != 0 && ((size_t(L.tile_mask) + 1) % kChunk) != 0))
       return fail(NOS_ERR_INVALID_ARGUMENT, "streaming solve: layout not a multiple of the %zu-item chunk", kChunk);
@@ -1164,16 +1181,22 @@ int zero_pad_launch(int n_fields, const nos::TiledLayout& L, void* dst, hipStrea
 // the n_fields used doubles out of every record into a pinned planar chunk (converted to the dataset's element type),
 // the chunk's planes are copied straight into their final place in the planar layout while the threads pack the next
 // chunk.  Moves 120 (60) instead of 304 bytes per NDT record over PCIe; pays when there are enough host threads, so it
-// is chosen for large inputs only (see create_from_records).  Planar layout only.
+// is chosen for large inputs only (see create_from_records).  Planar planes and tiled layouts alike.
+// `pinned` is the staging image of one chunk: planar (tile_log2 = 0: field f of record j at f * chunk + j) or in the
+// dataset's tiled order (record j of the chunk at (j >> T) * n_fields * 2^T + f * 2^T + (j mod 2^T); chunks start on
+// tile boundaries), so that the image is one contiguous piece of the dataset.  [lo, lo + count) = this thread's records.
 template <typename T>
-void pack_range(const unsigned char* host, size_t stride, const nos::FieldOffsets& fo, int n_fields, size_t first, size_t count,
-                size_t chunk, T* pinned) {
-  for (size_t j = 0; j < count; ++j) {
+void pack_range(const unsigned char* host, size_t stride, const nos::FieldOffsets& fo, int n_fields, size_t first, size_t lo,
+                size_t count, size_t chunk, int tile_log2, T* pinned) {
+  const size_t tile = size_t(1) << tile_log2, mask = tile - 1;
+  for (size_t j = lo; j < lo + count; ++j) {
     const unsigned char* rec = host + (first + j) * stride;
+    T* dst = tile_log2 == 0 ? pinned + j : pinned + (j >> tile_log2) * (tile * size_t(n_fields)) + (j & mask);
+    const size_t pitch = tile_log2 == 0 ? chunk : tile;
     for (int f = 0; f < n_fields; ++f) {
       double v;
       memcpy(&v, rec + fo.off[f], sizeof v);
-      pinned[size_t(f) * chunk + j] = T(v);
+      dst[size_t(f) * pitch] = T(v);
     }
   }
 }
@@ -1207,6 +1230,7 @@ int ingest_host_pack(nos_ctx* ctx, nos_dataset* ds, Shard& sh, const unsigned ch
   void* const pinned2[2] = {slot.pack_pinned[0], slot.pack_pinned[1]};
   const int n_fields = ds->n_fields;
   const bool f64 = ds->dtype == NOS_F64;
+  const int tile_log2 = sh.layout.tile_stride == 0 ? 0 : int(sh.layout.tile_shift);  // 0 = planar planes
   std::vector<std::thread> pool;
   const int n_workers = (e == hipSuccess && n_chunks > 0) ? threads : 0;
   for (int w = 0; w < n_workers; ++w) {
@@ -1219,9 +1243,9 @@ int ingest_host_pack(nos_ctx* ctx, nos_dataset* ds, Shard& sh, const unsigned ch
         const size_t lo = std::min(count, size_t(w) * per), hi = std::min(count, lo + per);
         if (lo < hi) {
           if (f64)
-            pack_range<double>(host, stride, fo, n_fields, first + lo, hi - lo, chunk, static_cast<double*>(pinned2[c & 1]) + lo);
+            pack_range<double>(host, stride, fo, n_fields, first, lo, hi - lo, chunk, tile_log2, static_cast<double*>(pinned2[c & 1]));
           else
-            pack_range<float>(host, stride, fo, n_fields, first + lo, hi - lo, chunk, static_cast<float*>(pinned2[c & 1]) + lo);
+            pack_range<float>(host, stride, fo, n_fields, first, lo, hi - lo, chunk, tile_log2, static_cast<float*>(pinned2[c & 1]));
         }
         arrived.fetch_add(1, std::memory_order_release);
       }
@@ -1235,10 +1259,17 @@ int ingest_host_pack(nos_ctx* ctx, nos_dataset* ds, Shard& sh, const unsigned ch
     if (e != hipSuccess) break;
     go.store(long(c), std::memory_order_release);
     while (arrived.load(std::memory_order_acquire) < int(c + 1) * n_workers) std::this_thread::yield();
-    for (int f = 0; f < n_fields && e == hipSuccess; ++f) {
-      char* dst = static_cast<char*>(sh.data) + (size_t(f) * sh.layout.field_stride + first) * es;
-      const char* src = static_cast<const char*>(slot.pack_pinned[buf]) + size_t(f) * chunk * es;
-      e = hipMemcpyAsync(dst, src, count * es, hipMemcpyHostToDevice, slot.copy_stream);
+    if (tile_log2 == 0) {
+      for (int f = 0; f < n_fields && e == hipSuccess; ++f) {
+        char* dst = static_cast<char*>(sh.data) + (size_t(f) * sh.layout.field_stride + first) * es;
+        const char* src = static_cast<const char*>(slot.pack_pinned[buf]) + size_t(f) * chunk * es;
+        e = hipMemcpyAsync(dst, src, count * es, hipMemcpyHostToDevice, slot.copy_stream);
+      }
+    } else {  // the chunk's tiles are one contiguous piece of the dataset (the pads of the last tile are zeroed below)
+      const size_t tile = size_t(1) << tile_log2;
+      const size_t tiles = (count + tile - 1) / tile;
+      char* dst = static_cast<char*>(sh.data) + (first >> tile_log2) * sh.layout.tile_stride * es;
+      e = hipMemcpyAsync(dst, slot.pack_pinned[buf], tiles * sh.layout.tile_stride * es, hipMemcpyHostToDevice, slot.copy_stream);
     }
     if (e == hipSuccess) e = hipEventRecord(slot.pack_done[buf], slot.copy_stream);
     used[buf] = true;
@@ -1281,8 +1312,9 @@ int create_from_records(nos_ctx* ctx, int kind, size_t n, const void* records, s
   const std::string mode = ctx->settings.ingest == 1 ? "pack" : (ctx->settings.ingest == 2 ? "unpack" : "auto");
   const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
   int pack_threads = ctx->settings.ingest_threads > 0 ? ctx->settings.ingest_threads : int(std::min(16u, hw / 2));
-  const bool planar = ds->tile == 0;
-  const bool use_pack = planar && pack_threads >= 1 &&
+  // planar planes, or tiles that divide the 256 Ki-record chunk of the pack path (the fp32 default: 1 024-item tiles)
+  const bool packable = ds->tile == 0 || (ds->tile <= (size_t(256) << 10) && ((size_t(256) << 10) % ds->tile) == 0);
+  const bool use_pack = packable && pack_threads >= 1 &&
                         (mode == "pack" || (mode == "auto" && n >= size_t(800000) && pack_threads >= 8));
   size_t begin = 0;
   for (Shard& sh : ds->shards) {

@@ -163,10 +163,11 @@ def test_every_launch_geometry_and_layout_gives_the_same_sums(oracle):
     """Every compiled launch geometry on every dataset layout (planar planes, 1024- and 4096-item tiles; the fp32 default
     is the 1024-item tile, the fp64 default planar).  A geometry whose chunk does not divide the tile, or that is not
     compiled for the element type, must be refused with an error — never run.  The default build carries fp64 geometries
-    0, 1, 3 and fp32 0, 1, 8; a `make ALL_VARIANTS=1` build (tools/, nos_version() says so) all 7 + 11."""
+    0, 1, 3, 7 and fp32 1, 8, 11 (0 = the library's choice); a `make ALL_VARIANTS=1` build (tools/, nos_version() says so)
+    all of them."""
     from nonlinear_optimizer_for_slam_amd import _lib
     all_variants = b"all launch geometries" in _lib.hip_lib().nos_version()
-    compiled = {"f64": set(range(7)) if all_variants else {0, 1, 3}, "f32": set(range(11)) if all_variants else {0, 1, 8}}
+    compiled = {"f64": set(range(9)) if all_variants else {0, 1, 3, 7}, "f32": set(range(14)) if all_variants else {0, 1, 8, 11}}
     planes = synth.ndt_planes(123_457, 4000)
     loss = ("exponential", 1.0, 1.0)
     want = oracle.ndt6_accumulate(planes, R_TEST, T_TEST, loss)
@@ -176,17 +177,16 @@ def test_every_launch_geometry_and_layout_gives_the_same_sums(oracle):
         c.set_option("tile_log2", tile)
         for dtype, rtol in (("f64", RTOL_F64), ("f32", RTOL_F32)):
             ds = NdtDataset.from_planes(c, planes, dtype)
-            for variant in range(11):
+            for variant in range(14):
                 for bpc in (0, 1, 4):
                     c.set_launch(bpc, variant)
                     try:
                         got = ds.accumulate6(R_TEST, T_TEST, loss)
                     except RuntimeError:
-                        # not compiled for the element type, or the 2048-item chunk of fp32 geometry 6 on a 1024-item tile
-                        assert variant not in compiled[dtype] or (dtype == "f32" and variant == 6 and tile in (-1, 10))
+                        # not compiled for the element type, or a 2048-item chunk (fp32 geometries 6, 12) on a 1024-item tile
+                        assert variant not in compiled[dtype] or (dtype == "f32" and variant in (6, 12) and tile in (-1, 10))
                         refused += 1
                         continue
-                    # fp32 geometry 0 on a tiled layout is served by geometry 8 (the default follows the layout)
                     assert variant in compiled[dtype]
                     helpers.assert_normal_equations_close(got, want, 6, rtol)
                     ran += 1

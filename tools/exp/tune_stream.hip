@@ -156,6 +156,11 @@ void bench_reproj(size_t n, int num_cus) {
   RUN(8, 256, 2, false, 2);
   RUN(8, 256, 2, false, 1);
   RUN(2, 512, 2, 2, 1);
+  RUN(1, 512, 3, 3, 1);
+  RUN(2, 512, 2, 3, 1);
+  RUN(4, 512, 2, 3, 1);
+  RUN(1, 1024, 4, 3, 1);
+  RUN(2, 1024, 4, 3, 1);
 #undef RUN
   {  // the floor of the geometry: the same loads with no arithmetic
     using PS = StreamOnlyProblem<T, 5>;
@@ -221,6 +226,7 @@ void bench_ndt6(size_t n, int num_cus, int tile_log2) {
   run<PE, T, ITEMS, BLOCK, MINW, true, PF>(b, P, BPC, ref, "ndt6 nt items=" #ITEMS " block=" #BLOCK " minw=" #MINW " pf=" #PF " bpc=" #BPC)
   if constexpr (sizeof(T) == 4) {
     RUNN(2, 512, 2, 1, 1);
+    RUNN(2, 512, 2, 3, 1);
     RUNN(2, 512, 2, 2, 1);
     RUNN(2, 512, 2, 0, 1);
     RUNN(2, 256, 2, 2, 2);
@@ -235,6 +241,7 @@ void bench_ndt6(size_t n, int num_cus, int tile_log2) {
     }
   } else {
     RUNN(1, 512, 3, 0, 1);
+    RUNN(1, 512, 2, 3, 1);
     RUNN(1, 512, 2, 1, 1);
     RUNN(2, 512, 2, 0, 1);
   }
