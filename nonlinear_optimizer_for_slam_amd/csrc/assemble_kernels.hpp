@@ -1805,7 +1805,6 @@ __global__ __launch_bounds__(BLOCK) void solve_cluster_kernel(TiledLayout L, typ
   __shared__ int s_fast;  // 1 once every group has been seen to sit on one XCD: stage-1 units then stay in that XCD's L2
   __shared__ double red[kSlices][kCols];
   __shared__ double s_tot[kLmTotDoubles(kOut)];
-  __shared__ double s_pose[12];
   __shared__ double s_lmd_raw[(sizeof(LmDevice) + 7) / 8];  // this workgroup's copy of the loop state and settings
   LmDevice& s_lmd = *reinterpret_cast<LmDevice*>(s_lmd_raw);
   nos_host::LmState& s_state = s_lmd.st;
@@ -1874,10 +1873,6 @@ __global__ __launch_bounds__(BLOCK) void solve_cluster_kernel(TiledLayout L, typ
     s_fast = 0;
     // a launch that finds `abort` raised (the test hook raises it beforehand) gives up at once, like one whose wait timed out
     if (__hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) s_flag = 2;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) s_pose[k] = s_state.R[k];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) s_pose[9 + k] = s_state.t[k];
   }
   __syncthreads();
   const unsigned int group = blockIdx.x & 7u;
@@ -1902,14 +1897,14 @@ __global__ __launch_bounds__(BLOCK) void solve_cluster_kernel(TiledLayout L, typ
     // pose of this iteration from LDS → scalar registers
     if constexpr (kOut == 28) {
 #pragma unroll
-      for (int k = 0; k < 9; ++k) P.R[k] = T(uniform_load(&s_pose[k]));
+      for (int k = 0; k < 9; ++k) P.R[k] = T(uniform_load(&s_state.R[k]));
 #pragma unroll
-      for (int k = 0; k < 3; ++k) P.t[k] = T(uniform_load(&s_pose[9 + k]));
+      for (int k = 0; k < 3; ++k) P.t[k] = T(uniform_load(&s_state.t[k]));
     } else {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) P.R2[k] = T(uniform_load(&s_pose[k]));
+      for (int k = 0; k < 4; ++k) P.R2[k] = T(uniform_load(&s_state.R[k]));
 #pragma unroll
-      for (int k = 0; k < 2; ++k) P.t2[k] = T(uniform_load(&s_pose[9 + k]));
+      for (int k = 0; k < 2; ++k) P.t2[k] = T(uniform_load(&s_state.t[k]));
     }
     T acc[kOut];
 #pragma unroll
@@ -1961,6 +1956,8 @@ __global__ __launch_bounds__(BLOCK) void solve_cluster_kernel(TiledLayout L, typ
         if (uint32_t(j) < J) Problem::item(x[j], P, valid[j], acc);
     }
     if constexpr (LI > 0) {
+      // (fetching item j + 1 from LDS before item j is evaluated was tried and is SLOWER: reprojection 2 M 14.4 -> 15.4 us
+      //  per iteration, profiles/r03_ab_resident.txt — the second buffer costs the register items their interleaving)
       for (uint32_t j = RI; j < J; ++j) {
         T xi[kF];
 #pragma unroll
@@ -2136,10 +2133,6 @@ __global__ __launch_bounds__(BLOCK) void solve_cluster_kernel(TiledLayout L, typ
         if (blockIdx.x == 0 && cost_history != nullptr && executed < history_capacity)
           __hip_atomic_store(cost_history + executed, s_tot[kOut - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         lm_step_lane<kOut>(lds_ptr(s_tot), lds_ptr(&s_lmd));
-#pragma unroll
-        for (int k = 0; k < 9; ++k) s_pose[k] = s_state.R[k];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) s_pose[9 + k] = s_state.t[k];
         s_flag = s_state.done != 0 ? 1 : 0;
       }
     }

@@ -65,6 +65,7 @@ for stats_json in sorted(glob.glob(os.path.join(src, "prof_*_stats.json"))):
     base = os.path.basename(stats_json)[len("prof_"):-len("_stats.json")]
     problem, dtype = base.rsplit("_", 1)
     streaming = problem.endswith("stream")  # NOS_LM_CLUSTER=0 run: the launch-per-iteration kernel of the same problem
+    host_loop = problem.endswith("host")    # --loop host run: plain nos_*_accumulate launches
     stats = newest(os.path.join(src, "prof_%s_stats" % base, "*", "*_kernel_stats.csv"))
     if stats is None:
         continue
@@ -89,8 +90,9 @@ for stats_json in sorted(glob.glob(os.path.join(src, "prof_*_stats.json"))):
         "commit": commit,
         "command": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --problem %s --dtype %s --steps 60 "
                    "--warmup 10 --repeats 3 --no-cpu-baseline --no-strong-baseline --no-cold" % (problem, dtype),
-        "problem": problem[:-6] if streaming else problem, "dtype": dtype,
-        "mode": "one launch per iteration (NOS_LM_CLUSTER=0)" if streaming else "product default", "workload": bench["config"]["workload"], "points_per_gpu": n,
+        "problem": problem[:-6] if streaming else (problem[:-4] if host_loop else problem), "dtype": dtype,
+        "mode": ("one launch per iteration (NOS_LM_CLUSTER=0)" if streaming else
+                 ("host loop around nos_*_accumulate: the plain accumulate kernel (--loop host)" if host_loop else "product default")), "workload": bench["config"]["workload"], "points_per_gpu": n,
         "kernel": k["Name"], "rocprof_calls": int(k["Calls"]), "rocprof_avg_ns": float(k["AverageNs"]),
         "rocprof_min_ns": float(k["MinNs"]), "rocprof_max_ns": float(k["MaxNs"]),
         "bench_kernel_ms_same_run": bench["roofline"]["kernel_ms"], "bench_ms_per_step_same_run": bench["ms_per_step"],
