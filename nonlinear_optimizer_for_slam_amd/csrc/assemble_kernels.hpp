@@ -1763,17 +1763,27 @@ __device__ __forceinline__ void state_load_sc1(const LmDevice* lm, nos_host::LmS
 // How many correspondences a lane keeps resident for the whole solve: RI of them in REGISTERS (compile-time unrolled) and
 // up to LI more in LDS (dynamic allocation, [slot][field][lane] so that lanes read consecutive addresses).  One
 // 512-thread workgroup per CU → two waves per SIMD → 256 VGPRs per lane and ≈ 150 KB of the CU's 160 KB LDS:
-//   NDT fp64 (120 B / correspondence): 2 + 2 → 4 per lane → 524 288 correspondences on 256 CUs
-//   NDT fp32 ( 60 B)                  : 3 + 4 → 7         → 917 504   (more register items spill: checked with
-//                                                                    tools/kernel_resources.py)
+//   NDT fp64 (resident form 96 B / correspondence): 3 + 3 → 6 per lane → 786 432 correspondences on 256 CUs
+//   NDT fp32 (60 B, S kept)                        : 3 + 4 → 7         → 917 504
 //   reprojection fp64 (40 B)          : 9 + 7 → 16        → 2 097 152  (BASELINE.json configs[2]: 2 M)
 //   reprojection fp32 (20 B)          : 10 + 14 → 24      → 3 145 728
 // i.e. at these sizes an LM iteration touches neither HBM nor the caches: its cost is the item math plus one grid-wide
 // hand-off.  The first touch (one pass over the dataset) is paid once per solve.
+// What a RESIDENT NDT correspondence consists of: the solvers only ever need A = SᵀS of the sqrt-information (with
+// J = [S | S M]: s = eᵀAe, g = w [Ae ; MᵀAe], H = w [A, AM ; ·, MᵀAM] — Ndt6Problem::item_A / Ndt3Problem::item_A), so a
+// correspondence that stays on chip for the whole solve is converted ONCE, at first touch, from {p, mu, S (9)} to
+// {p, mu, A (6)}: 12 values instead of 15 per item (more items fit) and ≈ 35 % fewer instructions per item and iteration
+// (fp64: 233 → ≈ 150).  Streamed data keeps the 15 planes: it is read
+// once per iteration, the conversion would cost more than it saves.
+// fp64 only: the fp32 item function already works from A and measured SLOWER through item_A (900 000: 8.57 → 9.24 µs).
+template <int FIELDS, size_t ELEM>
+constexpr int resident_fields() {
+  return (FIELDS == 15 && ELEM == 8) ? 12 : FIELDS;
+}
 template <int FIELDS, int ELEM>
 struct ResidentShape;
 template <>
-struct ResidentShape<15, 8> { static constexpr int RI = 2, LI = 2; };
+struct ResidentShape<15, 8> { static constexpr int RI = 3, LI = 3; };
 template <>
 struct ResidentShape<15, 4> { static constexpr int RI = 3, LI = 4; };
 template <>
@@ -1799,7 +1809,9 @@ __global__ __launch_bounds__(BLOCK) void solve_cluster_kernel(TiledLayout L, typ
   constexpr int kCols = 32;
   constexpr int kSlices = BLOCK / kCols;
   const T* __restrict__ base = static_cast<const T*>(L.base);
-  extern __shared__ __align__(16) unsigned char resident_raw[];  // [items_per_lane - RI][kF][BLOCK] of T
+  constexpr bool kAForm = kF == 15 && sizeof(T) == 8 && SI == 0;     // resident fp64 NDT items hold A = SᵀS (6) instead of S (9)
+  constexpr int kRF = kAForm ? resident_fields<kF, sizeof(T)>() : kF;  // values per resident item
+  extern __shared__ __align__(16) unsigned char resident_raw[];  // [items_per_lane - RI][kRF][BLOCK] of T
   T* resident = reinterpret_cast<T*>(resident_raw);
   __shared__ int s_flag;  // 0 go on, 1 loop finished, 2 abort
   __shared__ int s_fast;  // 1 once every group has been seen to sit on one XCD: stage-1 units then stay in that XCD's L2
@@ -1817,7 +1829,7 @@ __global__ __launch_bounds__(BLOCK) void solve_cluster_kernel(TiledLayout L, typ
   [[maybe_unused]] constexpr int kXccCol = 28;
   [[maybe_unused]] const unsigned int my_xcc = xcc_id();
   const uint64_t block_base = uint64_t(blockIdx.x) * BLOCK * J;
-  auto fetch = [&](uint32_t j, T (&dst)[kF]) -> bool {
+  auto fetch = [&](uint32_t j, T (&dst)[kRF]) -> bool {
     const uint64_t i = block_base + uint64_t(j) * BLOCK + threadIdx.x;
     const bool ok = i < L.n;
     const uint64_t ic = ok ? i : 0;  // clamped address; the value is zeroed below
@@ -1825,11 +1837,38 @@ __global__ __launch_bounds__(BLOCK) void solve_cluster_kernel(TiledLayout L, typ
     T xt[kF][1];
 #pragma unroll
     for (int f = 0; f < kF; ++f) load_items<T, 1, false>(base + off + uint64_t(f) * L.field_stride, xt[f]);
+    if constexpr (kAForm) {
 #pragma unroll
-    for (int f = 0; f < kF; ++f) dst[f] = ok ? xt[f][0] : T(0);
+      for (int f = 0; f < 6; ++f) dst[f] = ok ? xt[f][0] : T(0);
+      int q = 6;
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = a; b < 3; ++b) {  // A(a, b) = sum over rows k of S(k, a) S(k, b);  a00 a01 a02 a11 a12 a22
+          const T v = fma(xt[6 + a][0], xt[6 + b][0], fma(xt[9 + a][0], xt[9 + b][0], xt[12 + a][0] * xt[12 + b][0]));
+          dst[q++] = ok ? v : T(0);
+        }
+    } else {
+#pragma unroll
+      for (int f = 0; f < kF; ++f) dst[f] = ok ? xt[f][0] : T(0);
+    }
     return ok;
   };
-  T x[RI > 0 ? RI : 1][kF];
+  // one resident item → the sums (NDT: the A form; reprojection: the item as it is)
+  auto evaluate_resident = [&](const T (&xi)[kRF], bool ok, T (&acc_)[kOut]) {
+    if constexpr (kAForm) {
+      const T p3[3] = {xi[0], xi[1], xi[2]}, mu3[3] = {xi[3], xi[4], xi[5]};
+      const T A6[6] = {xi[6], xi[7], xi[8], xi[9], xi[10], xi[11]};
+      (void)ok;  // pads are all-zero records: they contribute exactly nothing
+      Problem::item_A(p3, mu3, A6, P, acc_);
+    } else {
+      T xf[kF];
+#pragma unroll
+      for (int f = 0; f < kF; ++f) xf[f] = xi[f < kRF ? f : 0];
+      Problem::item(xf, P, ok, acc_);
+    }
+  };
+  T x[RI > 0 ? RI : 1][kRF];
   bool valid[RI > 0 ? RI : 1];
   static_assert(SI == 0 || (RI == 0 && LI == 0), "the streaming form keeps nothing resident");
   // streaming form: the chunk being evaluated next (the first one of every iteration is fetched ahead of time)
@@ -1852,15 +1891,15 @@ __global__ __launch_bounds__(BLOCK) void solve_cluster_kernel(TiledLayout L, typ
       valid[j] = fetch(uint32_t(j), x[j]);
     } else {
 #pragma unroll
-      for (int f = 0; f < kF; ++f) x[j][f] = T(0);
+      for (int f = 0; f < kRF; ++f) x[j][f] = T(0);
     }
   }
   if constexpr (LI > 0) {
     for (uint32_t j = RI; j < J; ++j) {
-      T xi[kF];
+      T xi[kRF];
       (void)fetch(j, xi);
 #pragma unroll
-      for (int f = 0; f < kF; ++f) resident[(size_t(j - RI) * kF + f) * BLOCK + threadIdx.x] = xi[f];
+      for (int f = 0; f < kRF; ++f) resident[(size_t(j - RI) * kRF + f) * BLOCK + threadIdx.x] = xi[f];
     }
   }
 #ifdef NOS_LM_TIMING
@@ -1949,20 +1988,20 @@ __global__ __launch_bounds__(BLOCK) void solve_cluster_kernel(TiledLayout L, typ
     // (fp64 only: the fp32 kernels spill when their items are interleaved)
     if (sizeof(T) == 8 && J >= uint32_t(RI)) {  // grid-uniform; one straight-line block, so the scheduler can interleave the items
 #pragma unroll
-      for (int j = 0; j < RI; ++j) Problem::item(x[j], P, valid[j], acc);
+      for (int j = 0; j < RI; ++j) evaluate_resident(x[j], valid[j], acc);
     } else {
 #pragma unroll
       for (int j = 0; j < RI; ++j)
-        if (uint32_t(j) < J) Problem::item(x[j], P, valid[j], acc);
+        if (uint32_t(j) < J) evaluate_resident(x[j], valid[j], acc);
     }
     if constexpr (LI > 0) {
       // (fetching item j + 1 from LDS before item j is evaluated was tried and is SLOWER: reprojection 2 M 14.4 -> 15.4 us
       //  per iteration, profiles/r03_ab_resident.txt — the second buffer costs the register items their interleaving)
       for (uint32_t j = RI; j < J; ++j) {
-        T xi[kF];
+        T xi[kRF];
 #pragma unroll
-        for (int f = 0; f < kF; ++f) xi[f] = resident[(size_t(j - RI) * kF + f) * BLOCK + threadIdx.x];
-        Problem::item(xi, P, (block_base + uint64_t(j) * BLOCK + threadIdx.x) < L.n, acc);
+        for (int f = 0; f < kRF; ++f) xi[f] = resident[(size_t(j - RI) * kRF + f) * BLOCK + threadIdx.x];
+        evaluate_resident(xi, (block_base + uint64_t(j) * BLOCK + threadIdx.x) < L.n, acc);
       }
     }
     double dacc[kOut];

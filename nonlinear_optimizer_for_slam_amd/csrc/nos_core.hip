@@ -300,7 +300,7 @@ int launch_single(const nos::TiledLayout& L, const typename Problem::Params& P, 
     const auto kernel = a.protocol == 0 ? nos::solve_cluster_kernel<Problem, T, kBlock, Shape::RI, Shape::LI, 0>
                                         : nos::solve_cluster_kernel<Problem, T, kBlock, Shape::RI, Shape::LI, 1>;
     const size_t lds_items = a.items_per_lane > Shape::RI ? size_t(a.items_per_lane - Shape::RI) : 0;
-    const size_t dyn_bytes = lds_items * size_t(Problem::kFields) * kBlock * sizeof(T);
+    const size_t dyn_bytes = lds_items * size_t(nos::resident_fields<Problem::kFields, sizeof(T)>()) * kBlock * sizeof(T);
     // Dynamic LDS beyond the default limit has to be granted per kernel AND per device (the attribute belongs to the
     // function on the current device): asked for on every launch that needs it — a host-side call of about a microsecond,
     // once per solve — instead of remembered in a process-wide static that a second device or thread would trip over.

@@ -476,9 +476,9 @@ def test_beyond_the_resident_capacity_the_one_launch_solve_streams_and_agrees_wi
     """What the chip cannot keep resident is streamed from HBM every iteration — still inside one launch — and gives the
     launch-per-iteration loop's answer (lm_cluster=4: resident form only, so that loop runs); both orders of summation are
     fixed, they differ from each other in the last bits only."""
-    planes = synth.ndt_planes(600_000, 9000)  # > 4 x 131072: beyond the fp64 capacity; fp32 gets 1_000_000 below
-    for dtype, n, atol in (("f64", 600_000, 1e-12), ("f32", 1_000_000, 2e-6)):
-        p = planes if n == 600_000 else synth.ndt_planes(n, 15000)
+    planes = synth.ndt_planes(900_000, 9000)  # > 6 x 131072: beyond the fp64 capacity; fp32 (7 x 131072) gets 1_200_000 below
+    for dtype, n, atol in (("f64", 900_000, 1e-12), ("f32", 1_200_000, 2e-6)):
+        p = planes if n == 900_000 else synth.ndt_planes(n, 15000)
         ds = NdtDataset.from_planes(ctx, p, dtype)
         R1, t1, r1 = ds.solve6(np.eye(3), np.zeros(3), EXP, max_iterations=12)
         assert r1["launches"] == 1 and r1["ok"]

@@ -399,6 +399,40 @@ def test_c_abi_argument_errors_are_reported_not_crashed(ctx):
     rp.close()
 
 
+def test_options_are_range_checked_and_two_contexts_share_a_device(oracle):
+    """(a) nos_ctx_set_option refuses values outside an option's range instead of storing nonsense (a negative
+    plane skew used to become a huge stride); (b) the dynamic-LDS grant of the resident solve is asked for per launch, not
+    remembered in a process-wide static: a SECOND context on the device runs a resident solve that needs > 64 KB of LDS
+    right after the first one did, and a launch-geometry query names what ran."""
+    from nonlinear_optimizer_for_slam_amd import _lib
+    a = Context((0,))
+    for key, bad in (("plane_skew", -5), ("lm_cluster", 9), ("lm_window", 0), ("tile_log2", 3), ("pgo_agg", 1),
+                     ("map_eigen_version", 35), ("debug_cluster_abort", 2), ("nt", -2)):
+        with pytest.raises(_lib.NosError) as err:
+            a.set_option(key, bad)
+        assert err.value.status == 1, key
+    a.set_option("plane_skew", 0)
+    assert a.get_option("plane_skew") == 0
+    a.set_option("plane_skew", 1088)
+    with pytest.raises(_lib.NosError):
+        a.set_option("no_such_option", 1)
+    n = 700_000  # 6 correspondences per lane: three of them in LDS (3 x 12 x 512 x 8 B = 147 KB of dynamic LDS)
+    planes = synth.ndt_planes(n, 7000)
+    loss = ("exponential", 1.0, 1.0)
+    want = oracle.ndt6_solve(planes, np.zeros(3), np.eye(3), loss=loss, linear_solver=1)
+    b = Context((0,))
+    for c in (a, b, a):
+        ds = NdtDataset.from_planes(c, planes, "f64")
+        R, t, rep = ds.solve6(np.eye(3), np.zeros(3), loss, max_iterations=40)
+        assert rep["launches"] == 1 and rep["iterations"] == want["iterations"]
+        assert "solve_cluster_kernel<nos::Ndt6Problem<double, 1>, double, 512, 3, 3" in c.last_kernel()
+        dt, dq = helpers.pose_delta(R.reshape(3, 3), t, want["R"], want["t"])
+        assert dt < 1e-9 and dq < 1e-9
+        ds.close()
+    b.close()
+    a.close()
+
+
 def test_eighty_million_correspondences_on_one_gpu(ctx):
     """Largest BASELINE.json size (configs[3]: 80 M correspondences) resident on ONE device as fp32 storage
     (4.8 GB): additivity over a 3-way split, so the single-GPU strong-scaling baseline is known to be right."""

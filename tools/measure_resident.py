@@ -32,7 +32,7 @@ def per_iter_us(solve, k=400, reps=5):
 
 
 cases = [("reproj", "f64", n) for n in (131_072, 500_000, 1_000_000, 2_000_000)] + [("reproj", "f32", 2_000_000), ("reproj", "f32", 3_000_000)] + \
-        [("ndt6", "f64", n) for n in (131_072, 262_144, 500_000)] + [("ndt6", "f32", 900_000), ("ndt3", "f64", 500_000)] + \
+        [("ndt6", "f64", n) for n in (100_000, 131_072, 262_144, 500_000, 786_432)] + [("ndt6", "f32", 900_000), ("ndt3", "f64", 500_000)] + \
         [("ndt6", "f64", 1_000_000), ("ndt6", "f64", 4_000_000), ("ndt6", "f32", 4_000_000), ("reproj", "f64", 4_000_000)]  # streamed
 for kind, dtype, n in cases:
     if kind == "reproj":
@@ -47,7 +47,7 @@ for kind, dtype, n in cases:
     res, l1 = per_iter_us(fn)
     with ctx.options(lm_cluster=0):
         per, l2 = per_iter_us(fn)
-    cap = {("ndt6", "f64"): 524_288, ("ndt3", "f64"): 524_288, ("ndt6", "f32"): 917_504, ("reproj", "f64"): 2_097_152,
+    cap = {("ndt6", "f64"): 786_432, ("ndt3", "f64"): 786_432, ("ndt6", "f32"): 917_504, ("reproj", "f64"): 2_097_152,
            ("reproj", "f32"): 3_145_728}[(kind, dtype)]
     print(json.dumps({"problem": kind, "dtype": dtype, "n": n, "one_launch_form": "resident on chip" if n <= cap else "streamed",
                       "resident_us_per_iteration": res, "resident_launches": l1,
