@@ -1013,17 +1013,17 @@ __device__ __forceinline__ bool lm_prologue(const FusedFinal& fin, Params& P) {
 // every device form of the loop runs it (launch per iteration, stand-alone step kernel, single workgroup, one-launch
 // resident / streamed).  Round 2 had that function inlined into the kernels; unrolled for instruction-level parallelism it
 // wanted ≈ 230 VGPRs (a 6x6 system, its factor, the sums, the state), which pinned every kernel that contained it at the
-// 256-register ceiling and made the streaming kernels spill around it.  Now it is two NOINLINE functions called by lane 0,
-// handing over through LDS — the damped solve (nos_host::DampedStep itself, ≈ 120 VGPRs) and the O(1) rest (pose update,
-// convergence tests, λ schedule) — so a kernel's own allocation is set by its hot loop and what it keeps alive across the
-// call (the streaming kernels: the prefetched first chunk of the next iteration).  A wave-parallel elimination (one matrix
+// 256-register ceiling and made the streaming kernels spill around it.  Now it is ONE NOINLINE function called by lane 0 —
+// the damped solve (nos_host::DampedStep itself), a scheduling barrier, then the O(1) rest (pose update, convergence tests,
+// λ schedule): 117 VGPRs — so a kernel's own allocation is set by its hot loop and what it keeps alive across the call
+// (the streaming kernels: the prefetched first chunk of the next iteration).  A wave-parallel elimination (one matrix
 // element per lane, pivots by v_readlane, operands by ds_bpermute) was built and measured first: it needs only ≈ 40
 // registers but turns the step into ONE dependent chain — 2.45 µs against the 1.5 µs of the single lane's interleaved
 // chains (profiles/r03_lm_step_forms.txt) — so the single lane stayed.
-// `tot` is LDS: [0, NOUT) the sums, [NOUT, NOUT + N) receives the step, [NOUT + 7] 1.0 if the solve succeeded.
+// `tot` (the NOUT sums) and `lmd` (loop state and settings) are LDS.
 using LdsDouble = __attribute__((address_space(3))) double;
 using LdsLmDevice = __attribute__((address_space(3))) LmDevice;
-constexpr int kLmTotDoubles(int n_out) { return n_out + 8; }
+constexpr int kLmTotDoubles(int n_out) { return n_out; }
 
 __device__ __forceinline__ void wave_sync_lds() {
   // LDS instructions of one wave execute in issue order; this only keeps the compiler from moving accesses across
@@ -1057,20 +1057,12 @@ __device__ __forceinline__ void series_cos_sinc(double v, double* c_out, double*
 
 // First half: δ = -(H with its diagonal scaled by 1 + λ)^-1 g — nos_host::DampedStep, the host loop's own function
 // (right-looking LDLT with reciprocal pivots; on the device the reciprocal is the hardware seed + two Newton steps).
-template <int NOUT>
-__device__ __attribute__((noinline)) void lm_solve_lane(LdsDouble* tot, double lambda) {
-  constexpr int N = NOUT == 28 ? 6 : 3;
-#ifdef NOS_LM_TIMING
-  unsigned long long tick_ = clock64();
-#endif
-  double out[NOUT - 1], step[N];
+template <int NOUT, int N>
+__device__ __forceinline__ bool lm_solve_lane(const LdsDouble* tot, double lambda, double (&step)[N]) {
+  double out[NOUT - 1];
 #pragma unroll
   for (int k = 0; k < NOUT - 1; ++k) out[k] = tot[k];
-  const bool solved = nos_host::DampedStep<N>(out, lambda, step);
-#pragma unroll
-  for (int r = 0; r < N; ++r) tot[NOUT + r] = step[r];
-  tot[NOUT + 7] = solved ? 1.0 : 0.0;
-  NOS_STEP_TICK(0)
+  return nos_host::DampedStep<N>(out, lambda, step);
 }
 
 // Second half: pose update, the two convergence tests (after the update, as in the reference), λ schedule — the rest of
@@ -1078,9 +1070,8 @@ __device__ __attribute__((noinline)) void lm_solve_lane(LdsDouble* tot, double l
 // costs 8 cycles whatever it computes: the exponential map's two factors are even in θ and are summed as power series for
 // θ < 1/8 (no square root, no argument reduction, no division; sincos beyond), normalisation by reciprocal square root (seed
 // + two Newton steps), the tests on squared norms.  Within an ulp or two of the host loop's libm calls per operation.
-template <int NOUT>
-__device__ __attribute__((noinline)) void lm_finish_lane(const LdsDouble* tot, LdsLmDevice* lmd) {
-  constexpr int N = NOUT == 28 ? 6 : 3;
+template <int NOUT, int N>
+__device__ __forceinline__ void lm_finish_lane(const LdsDouble* tot, LdsLmDevice* lmd, const double (&step)[N], bool solved) {
 #ifdef NOS_LM_TIMING
   unsigned long long tick_ = clock64();
 #endif
@@ -1088,11 +1079,9 @@ __device__ __attribute__((noinline)) void lm_finish_lane(const LdsDouble* tot, L
   const int iteration = lmd->st.iteration;
   const int max_iterations = lmd->settings.max_iterations, float_schedule = lmd->settings.float_schedule;
   const double gtol = lmd->settings.gradient_tolerance, ptol = lmd->settings.parameter_tolerance;
-  const bool solved = tot[NOUT + 7] != 0.0;
-  double step[N], g2 = 0.0, s2 = 0.0;
+  double g2 = 0.0, s2 = 0.0;
 #pragma unroll
   for (int r = 0; r < N; ++r) {
-    step[r] = tot[NOUT + r];
     const double gr = tot[N * (N + 1) / 2 + r];
     g2 = __builtin_fma(gr, gr, g2);
     s2 = __builtin_fma(step[r], step[r], s2);
@@ -1175,9 +1164,17 @@ __device__ __attribute__((noinline)) void lm_finish_lane(const LdsDouble* tot, L
 
 // The loop body; call with ONE lane.
 template <int NOUT>
-__device__ __forceinline__ void lm_step_lane(LdsDouble* tot, LdsLmDevice* lmd) {
-  lm_solve_lane<NOUT>(tot, lmd->st.lambda);
-  lm_finish_lane<NOUT>(tot, lmd);
+__device__ __attribute__((noinline)) void lm_step_lane(const LdsDouble* tot, LdsLmDevice* lmd) {
+  constexpr int N = NOUT == 28 ? 6 : 3;
+#ifdef NOS_LM_TIMING
+  unsigned long long tick_ = clock64();
+#endif
+  double step[N];
+  const bool solved = lm_solve_lane<NOUT, N>(tot, lmd->st.lambda, step);
+  NOS_STEP_TICK(0)
+  // the scheduler must not weave the two halves into each other: together they would want ≈ 230 registers again
+  __builtin_amdgcn_sched_barrier(0);
+  lm_finish_lane<NOUT, N>(tot, lmd, step, solved);
 }
 
 // LDS address of a __shared__ object (the generic pointer HIP hands out, narrowed back to its address space)

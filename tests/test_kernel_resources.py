@@ -2,8 +2,8 @@
 objects hipcc cross-compiled into csrc/*.o).
 
 Round 2's one-launch kernels carried the whole single-lane LM step inlined and sat at 256 VGPRs with 4-23 spilled
-registers; the step is now two noinline functions called by lane 0 (nos::lm_solve_lane / lm_finish_lane,
-csrc/assemble_kernels.hpp) whose registers are their own.  This test keeps it that way for every instantiation of the default build: ndt6 / ndt3 /
+registers; the step is now a noinline function called by lane 0 (nos::lm_step_lane, csrc/assemble_kernels.hpp)
+whose registers are its own.  This test keeps it that way for every instantiation of the default build: ndt6 / ndt3 /
 reprojection x fp64 / fp32 x {no loss, exponential, Huber}, launch-per-pass (assemble_kernel), single workgroup, resident
 and streamed one-launch forms (solve_cluster_kernel), the stand-alone step kernel — and for the other translation units.
 """
