@@ -78,6 +78,31 @@ def test_reproj_matches_oracle(ctx, oracle, dtype, rtol, loss):
     ds.close()
 
 
+@pytest.mark.parametrize("n", [0, 1, 511, 513, 131_071, 262_145, 393_217, 450_001, 700_003, 1_048_583])
+def test_reprojection_ping_pong_kernel_at_every_trip_count(ctx, oracle, n):
+    """The launch-per-pass reprojection kernel is the ping-pong form (two register buffers, loop unrolled twice, peeled
+    tail): with one 512-thread workgroup per CU a workgroup takes 0, 1, 2, 3, 4, 5-6 or 8-9 chunks at these sizes — every
+    path through the prologue, the unrolled body (odd and even trip counts) and the epilogue — and the sums must be the
+    oracle's, with behind-camera points and a ragged tail; both element types."""
+    planes = synth.reproj_planes(max(n, 1))[:, :n]
+    if n > 200:
+        planes[2, 50:150] = -2.0
+    R = helpers.rot_xyz(0.0, 0.01, -0.08)
+    t = np.array([0.08, -0.1, 0.4])
+    loss = ("huber", synth.REPROJ_HUBER_THRESHOLD)
+    want = oracle.reproj_accumulate(planes, R, t, synth.REPROJ_INTR4, loss) if n > 0 else np.zeros(28)
+    for dtype, rtol in (("f64", RTOL_F64), ("f32", 2e-6)):
+        ds = ReprojDataset.from_planes(ctx, planes, dtype)
+        got = ds.accumulate(R, t, synth.REPROJ_INTR4, loss)
+        if n == 0:
+            assert np.all(got == 0.0)
+        else:
+            helpers.assert_normal_equations_close(got, want, 6, rtol)
+            assert ", 3>" in ctx.last_kernel() and "ReprojProblem" in ctx.last_kernel()  # the ping-pong instantiation ran
+        assert np.array_equal(got, ds.accumulate(R, t, synth.REPROJ_INTR4, loss))  # bit-repeatable
+        ds.close()
+
+
 def test_empty_dataset_gives_zero_sums(ctx):
     planes = np.zeros((15, 0))
     ds = NdtDataset.from_planes(ctx, planes, "f64")
@@ -168,7 +193,7 @@ def test_every_launch_geometry_and_layout_gives_the_same_sums(oracle):
     from nonlinear_optimizer_for_slam_amd import _lib
     all_variants = b"all launch geometries" in _lib.hip_lib().nos_version()
     compiled = {"f64": set(range(9)) if all_variants else {0, 1, 3, 7}, "f32": set(range(14)) if all_variants else {0, 1, 8, 11}}
-    planes = synth.ndt_planes(123_457, 4000)
+    planes = synth.ndt_planes(423_457, 4000)  # 3-4 chunks per workgroup at one 512-thread workgroup per CU: loop bodies run
     loss = ("exponential", 1.0, 1.0)
     want = oracle.ndt6_accumulate(planes, R_TEST, T_TEST, loss)
     c = Context((0,))
