@@ -776,7 +776,9 @@ __device__ __forceinline__ void tagged_store(TaggedUnit* p, double value, unsign
   w[1] = (unsigned int)(bits >> 32);
   w[2] = (unsigned int)(seq & 0xFFFFFFFFull);
   w[3] = (unsigned int)(seq >> 32);
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(w) : "memory");
+  // (s_nop 1 inside the string: a 16-byte store reads its data registers up to two states after issue and hipcc pads
+  //  nothing around inline asm — without it the next instruction may overwrite them; cdna_hip_programming.md §5.7 item 1)
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(w) : "memory");
 }
 // The same unit with a PLAIN store: the line stays in the storing CU's XCD L2, where a reader on the SAME XCD finds it with its
 // sc1 load (L1-bypassing, L2-served) without the trip through the fabric; a reader on another XCD never sees it.
@@ -788,7 +790,7 @@ __device__ __forceinline__ void tagged_store_plain(TaggedUnit* p, double value, 
   w[1] = (unsigned int)(bits >> 32);
   w[2] = (unsigned int)(seq & 0xFFFFFFFFull);
   w[3] = (unsigned int)(seq >> 32);
-  asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(w) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(w) : "memory");
 }
 // XCD (XCC) this wave runs on, 0…7
 __device__ __forceinline__ unsigned int xcc_id() {
