@@ -12,6 +12,7 @@ identical seeded inputs.  Tolerances (written here, used below):
                                                          gap, results/maha_amd64_simple.txt:24-25)
   final pose, fp64 LM loop                              : 1e-6 (north star), expected ~1e-10
 """
+import os
 import numpy as np
 import pytest
 
@@ -706,3 +707,39 @@ def test_two_threads_each_owning_a_solver_get_the_single_thread_answers(oracle):
     for th in threads:
         th.join()
     assert not errors, errors[:5]
+
+
+# ---------------------------------------------------------------- the bench line
+
+def test_bench_line_carries_the_contract_fields():
+    """`python bench.py` prints ONE JSON line; the driver and the judge read fixed keys from it.  A short run (1 M
+    correspondences, small CPU sample) must carry every one of them with sane values: throughput = points / time,
+    roofline fraction = algorithmic bytes / kernel time / 8 TB/s, a CPU baseline with its core count and sample."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "30", "--warmup", "5", "--repeats", "2",
+           "--points", "1000000", "--prewarm-ms", "50", "--cpu-seconds", "0.5", "--no-strong-baseline", "--no-cold"]
+    run = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert run.returncode == 0, run.stderr[-2000:]
+    lines = [l for l in run.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines  # one line on stdout, everything else on stderr
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 30 and d["warmup"] == 5 and d["higher_is_better"] is True
+    assert d["dtype"] == "f64" and d["vs_baseline"] is None and "synthetic" in d["data"] and "workload" in d["config"]
+    assert abs(d["value"] - 1_000_000 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    r = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"):
+        assert key in r, key
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.0 < r["frac"] < 1.0
+    assert abs(r["algorithmic_bytes_per_launch"] - 120 * 1_000_000) < 1  # SURVEY §8(d): 120 B per fp64 NDT correspondence
+    assert "Ndt6Problem<double" in r["kernel"]  # the symbol the library launched, not a description
+    c = d["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in c, key
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
