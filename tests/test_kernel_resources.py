@@ -56,3 +56,27 @@ def test_other_translation_units_report(obj):
     # known and off the hot path: the voxel-indexed two-slot kernels (three-stage software pipeline) and the set-up kernel
     # of the pose-graph coarse level's block cyclic reduction (6x6 blocks in registers, once per LM iteration)
     assert all("assemble_indexed_kernel" in n or "pgo_pcr_setup_kernel" in n for n in spilling), spilling
+
+
+def test_inline_asm_16_byte_stores_carry_their_wait_states():
+    """hipcc pads nothing around inline asm, and a 16-byte store reads its data registers up to two states after issue:
+    the tagged all-reduce's `global_store_dwordx4 … sc1` statements end with `s_nop 1` inside the string
+    (cdna_hip_programming.md §5.7) — without it the next instruction may overwrite the registers, which once cost four
+    sums their low words.  Every write-through 16-byte store in the code object (they only come from that inline asm) must
+    be followed by the nop."""
+    import re
+    import subprocess
+    import tempfile
+    llvm = "/opt/rocm/lib/llvm/bin"
+    obj = os.path.join(CSRC, "nos_core.o")
+    with tempfile.TemporaryDirectory() as d:
+        fat, co = os.path.join(d, "fatbin"), os.path.join(d, "co")
+        subprocess.check_call([llvm + "/llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, obj])
+        subprocess.check_call([llvm + "/clang-offload-bundler", "--type=o", "--input=" + fat,
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co, "--unbundle"])
+        txt = subprocess.run([llvm + "/llvm-objdump", "-d", "--no-show-raw-insn", co], capture_output=True, text=True).stdout
+    lines = [l.strip() for l in txt.splitlines() if l[:1] in ("\t", " ")]
+    stores = [i for i, l in enumerate(lines) if re.match(r"global_store_dwordx4 .* sc1", l)]
+    assert len(stores) >= 36, len(stores)  # at least one per one-launch solve kernel
+    bare = [lines[i:i + 2] for i in stores if not lines[i + 1].startswith("s_nop 1")]
+    assert not bare, bare[:3]
