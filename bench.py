@@ -59,7 +59,11 @@ def parse_args():
                     help="untimed GPU activity (the same iteration) before the warm-up steps: the part needs ≈ 0.1-0.3 s "
                          "of load to reach its steady clocks; reported as prewarm_ms")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="time budget per CPU baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=1.2,
+                    help="time budget of the longest CPU baseline leg of the headline (its thread-count sweep takes ≈ 4.5x this; "
+                         "the other configurations and stages get one short leg each: ≤ 10 s of CPU baselines in the default run)")
+    ap.add_argument("--no-stages", action="store_true",
+                    help="skip the stage lines (pose graph, matcher, map build, ingestion, reference wrappers: bench_stages.py)")
     ap.add_argument("--no-strong-baseline", action="store_true",
                     help="skip the 80 M-correspondence single-GPU pass (denominator of the 8-GPU strong-scaling claim)")
     ap.add_argument("--strong-points", type=int, default=80_000_000)
@@ -337,6 +341,30 @@ def cpu_baseline(work, planes, seconds):
     scalar = {"value": ns * passes / el, "unit": "corr/s", "cores": 1, "kind": "port",
               "sample": "%d passes over the first %d correspondences, scalar fp64 (%s)" % (passes, ns, scalar_cite)}
     return avx, scalar, avx64
+
+
+def cpu_baseline_single(work, planes, budget):
+    """ONE short CPU leg for the lines of the other configurations: the same-precision AVX restatement at min(32, cores)
+    threads (the fastest count of the headline's sweep on every box so far); the thread-count sweep is the headline's."""
+    from oracle import loader as oracle
+    n = planes.shape[1]
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = max(1, min(32, avail, int(os.environ.get("NOS_BENCH_CPU_THREADS", str(avail)))))
+    fp64_fn = work.cpu_leg_fp64_avx(oracle) if (work.dtype == "f64" and getattr(work, "cpu_leg_fp64_avx", None) is not None) else None
+    if fp64_fn is not None:
+        fn, data, what = (lambda: fp64_fn(planes, threads)), planes, "AVX2+FMA 4-lane fp64 (SolveDouble restated)"
+    else:
+        avx_fn, _, avx_cite, _ = work.cpu_legs(oracle, planes)
+        p32 = planes.astype(np.float32)
+        fn, data, what = (lambda: avx_fn(p32, threads)), p32, "AVX2+FMA fp32 lanes (%s)" % avx_cite
+    fn()
+    passes, t0 = 0, time.perf_counter()
+    while passes < 2 or time.perf_counter() - t0 < budget:
+        fn()
+        passes += 1
+    el = time.perf_counter() - t0
+    return {"value": n * passes / el, "unit": "corr/s", "cores": threads, "kind": "port",
+            "sample": "%d full passes over the same %d correspondences, %s, %d threads" % (passes, n, what, threads)}
 
 
 class _StdoutToStderr:
@@ -649,13 +677,14 @@ def main():
     other_configs = None
     if dist is None and other_wanted and planes is not None:
         other_configs = {}
-        specs = [("reproj_f64_2M (BASELINE.json configs[2])", "reproj", "f64", 2_000_000),
-                 ("ndt6_f64_100k (BASELINE.json configs[0] shape on the GPU)", "ndt6", "f64", 100_000),
-                 ("ndt6_f32_10M (configs[1] data, fp32 storage = the reference's SIMD classes)", "ndt6", "f32", n_local),
-                 ("ndt3_f64_10M (configs[1] data through the planar solver)", "ndt3", "f64", n_local)]
-        for label, problem, dtype, points in specs:
+        specs = [("reproj_f64_2M (BASELINE.json configs[2])", "reproj", "f64", 2_000_000, "flat"),
+                 ("ndt6_f64_100k (BASELINE.json configs[0] shape on the GPU)", "ndt6", "f64", 100_000, "flat"),
+                 ("ndt6_f32_10M (configs[1] data, fp32 storage = the reference's SIMD classes)", "ndt6", "f32", n_local, "flat"),
+                 ("ndt3_f64_10M (configs[1] data through the planar solver)", "ndt3", "f64", n_local, "flat"),
+                 ("indexed_10M (configs[1] data in the voxel-indexed layout, one slot, fp64)", "ndt6", "f64", n_local, "indexed")]
+        for label, problem, dtype, points, layout in specs:
             a2 = argparse.Namespace(**vars(args))
-            a2.problem, a2.dtype, a2.points, a2.layout = problem, dtype, points, "flat"
+            a2.problem, a2.dtype, a2.points, a2.layout = problem, dtype, points, layout
             w2 = WORKLOADS[problem](a2, pkg)
             p2 = w2.planes(points, 0) if problem == "reproj" else (planes if points == n_local else np.ascontiguousarray(planes[:, :points]))
             d2 = w2.dataset(ctx, p2)
@@ -673,55 +702,30 @@ def main():
                      "launches_per_train": getattr(w2, "launches_of_last_solve", None), "kernel": sym,
                      "kernel_ms_bracket": leg["kernel_ms"], "final_translation_error_m": leg["final_translation_error_m"],
                      "timing": "as the headline: trains of K steps bracketed by device synchronisation; median of 3"}
+            if layout == "indexed":
+                entry["bytes_note"] = ("ADDITIVE voxel-indexed layout: its own bytes (24 B point + 4 B voxel id per point; the 25 MB "
+                                       "voxel table is cache resident) — never compared with the 120-byte roofline of the flat "
+                                       "layout; the bound is vector-ALU issue (valu_floor_ms)")
             if not args.no_cpu_baseline:
-                avx2, scalar2, avx64_2 = cpu_baseline(w2, p2, 1.0)
-                entry["cpu_baseline"] = avx2
-                entry["cpu_baseline_scalar_fp64"] = scalar2
-                if avx64_2 is not None:
-                    entry["cpu_baseline_fp64_avx"] = avx64_2
+                entry["cpu_baseline"] = cpu_baseline_single(w2, planes if points == n_local and problem != "reproj" else p2, 0.25)
             other_configs[label] = entry
             d2.close()
             del p2
 
-    # ---- BASELINE.json configs[4]: pose-graph optimisation, 1 M poses / ~4 M relative-pose constraints
-    if other_configs is not None:
-        from nonlinear_optimizer_for_slam_amd import pgo
-        t0 = time.perf_counter()
-        graph = synth.pose_graph(1_000_000, 3)
-        t_gen = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        g = pgo.PoseGraph(ctx, graph["init"], graph["ref"], graph["qry"], graph["meas"], None, None, graph["fixed"])
-        t_create = time.perf_counter() - t0
-        g.linearize()
-        lin = []
-        for _ in range(5):
-            ctx.synchronize()
-            t0 = time.perf_counter()
-            cost0, gnorm0 = g.linearize()  # blocking: residuals + analytic Jacobians + block-sparse J^T J and J^T r
-            lin.append(1e3 * (time.perf_counter() - t0))
-        t0 = time.perf_counter()
-        pcg_it, pcg_res, _ = g.solve(1e-3, 300, 1e-6)
-        t_pcg = 1e3 * (time.perf_counter() - t0)
-        t0 = time.perf_counter()
-        lm_it, hist = g.optimize(max_iterations=3, gradient_tolerance=1e-6, parameter_tolerance=1e-6, pcg_iterations=300,
-                                 pcg_tolerance=1e-6)
-        t_lm = 1e3 * (time.perf_counter() - t0)
-        cost1, gnorm1 = g.linearize()
-        m_edges = int(graph["ref"].size)
-        other_configs["pgo_1M_poses_4M_constraints (BASELINE.json configs[4])"] = {
-            "poses": 1_000_000, "constraints": m_edges, "dtype": "f64",
-            "linearize_ms": summarize(lin), "constraint_linearisations_per_s": m_edges / (min(lin) * 1e-3),
-            "pcg": {"lambda": 1e-3, "iterations_to_1e-6": int(pcg_it), "relative_residual": float(pcg_res), "ms": t_pcg,
-                    "ms_per_iteration": t_pcg / max(1, int(pcg_it)), "preconditioner": "two-level (block-Jacobi + rigid-motion coarse space)"},
-            "lm": {"iterations": int(lm_it) + 1, "ms": t_lm, "cost_before": float(cost0), "cost_after": float(cost1),
-                   "gradient_norm_before": float(gnorm0), "gradient_norm_after": float(gnorm1),
-                   "pcg_iterations_per_solve": [int(h[3]) for h in hist]},
-            "graph_generation_s": t_gen, "create_ms": 1e3 * t_create,
-            "timing": "host wall clock around blocking calls (each call ends with a device synchronisation)",
-            "parity": "unpinned against reference outputs (the reference has no analytic PGO and no captured run); "
-                      "tests/test_pgo.py checks the linearisation against an explicit assembly"}
-        g.close()
-        del graph
+    # ---- BASELINE.json configs[4] (pose graph) and the stages either side of the hot path: matcher, map build,
+    # ingestion, the reference's two published test wrappers — bench_stages.py, same run, same clock
+    stages = None
+    if other_configs is not None and not args.no_stages:
+        import bench_stages
+        want_cpu = not args.no_cpu_baseline
+        stages = {}
+        stages.update(bench_stages.stage_pgo(ctx, pkg, want_cpu))
+        other_configs["pgo_1M_poses_4M_constraints (BASELINE.json configs[4])"] = stages.pop(
+            "pgo_1M_poses_4M_constraints (BASELINE.json configs[4])")
+        stages.update(bench_stages.stage_matcher(ctx, pkg, planes, want_cpu))
+        stages.update(bench_stages.stage_ingest(ctx, pkg, planes, want_cpu))
+        stages.update(bench_stages.stage_mapbuild(ctx, pkg, want_cpu))
+        stages.update(bench_stages.stage_reference_wrappers(ctx, pkg, want_cpu))
 
     # ---- the denominator of the strong-scaling claim: configs[3]'s 80 M correspondences on ONE GPU
     strong = None
@@ -889,6 +893,36 @@ def main():
                                   "cpu_threads": same["cores"],
                                   "note": "same precision on both sides; a GPU / CPU ratio says nothing about kernel quality, "
                                           "the roofline fraction does"}
+    if stages is not None:
+        result["stages"] = stages
+    # LAST key, <= 1 KB: one [ms, fraction of the stage's bound] pair per line of this run, so that a log tail shows them all
+    def sig(x):
+        return float("%.4g" % x)
+    summary = {"ndt6_f64_10M": [sig(ms_med), sig(result["roofline"]["frac"])]}
+    if host_loop is not None:
+        summary["host_loop"] = [sig(host_loop["ms_per_step"]), sig(bytes_per_launch / (host_loop["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBPS)]
+    if strong is not None:
+        summary["strong_80M"] = [sig(strong["ms_per_step"]), sig(strong["points"] * 120 / (strong["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBPS)]
+    short = {"reproj_f64_2M": "reproj_2M", "ndt6_f64_100k": "ndt6_100k", "ndt6_f32_10M": "ndt6_f32", "ndt3_f64_10M": "ndt3",
+             "indexed_10M": "indexed"}
+    for label, entry in (other_configs or {}).items():
+        key = short.get(label.split(" ")[0])
+        if key is not None:
+            summary[key] = [sig(entry["ms_per_step"]["median"]), sig(entry["frac_hbm"])]
+    short = {"pgo_linearize": "pgo_lin", "pgo_matvec": "pgo_mv", "pgo_pcg_iteration": "pgo_it", "matcher_10M_unsorted": "match_uns",
+             "matcher_10M_cell_sorted": "match", "matcher_10M_cell_sorted_ids": "match_ids", "mapbuild_10M_100k_voxels": "map_100k",
+             "mapbuild_10M_796k_voxels": "map_796k", "mapbuild_reference_scene_exact": "map_ref", "mapbuild_reference_scene_wave_parallel":
+             "map_ref_wave", "ingest_10M_records_raw": "ing_raw", "ingest_10M_records_host_pack": "ing_pack", "ingest_10M_planes": "ing_planes"}
+    for label, entry in (stages or {}).items():
+        if label in short:
+            summary[short[label]] = [sig(entry["ms"]["median"]), sig(entry["frac"])]
+    if stages is not None:
+        w = stages["reference_wrapper_ndt"]
+        summary["wrap_ndt"] = [sig(w["ms"]["median"]), int(w["cost_lines_equal_the_captured_run"])]
+        w = stages["reference_wrapper_reproj"]
+        summary["wrap_reproj"] = [sig(w["ms"]["median"]), int(w["cost_line_equals_the_captured_run"])]
+    summary["_"] = "[ms, frac of the line's bound (hbm | pcie; wrappers: 1 = COST lines equal the captured run)]"
+    result["summary"] = summary
     if rank == 0:
         print(json.dumps(result), flush=True)
     if dist is not None:

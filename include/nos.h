@@ -411,6 +411,10 @@ int nos_pgo_get_state(nos_pose_graph* pg, double* poses, double* switches);
 int nos_pgo_get_vector(nos_pose_graph* pg, int which, double* out);
 /* y = (J^T J with its diagonal scaled by 1 + lambda) x for host vectors.  Diagnostics. */
 int nos_pgo_matvec(nos_pose_graph* pg, double lambda, const double* x, double* y);
+/* Timing aid (bench.py): `repeats` device-resident products of the kind a PCG iteration makes (x = the gradient of the
+ * last nos_pgo_linearize), back to back on the context's stream between one pair of HIP events → milliseconds per
+ * product.  which: 0 the product of a PCG iteration (with its in-launch p.Ap sum), 1 the linearisation sweeps. */
+int nos_pgo_time_sweep(nos_pose_graph* pg, int which, double lambda, int repeats, double* ms_per_sweep);
 
 /* ---- thread safety ----------------------------------------------------------------
  * Every entry point that takes a context, or an object created on one (dataset, map, scan, pose graph), holds that

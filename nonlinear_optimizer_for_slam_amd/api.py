@@ -500,7 +500,7 @@ class NdtMap:
 
     @classmethod
     def build(cls, ctx, points, voxel_resolution=1.0, search_radius_sq=1.0, proper_sqrt_information=True,
-              reference_exact=False):
+              reference_exact=False, return_stats=True):
         """Construct the map from raw points [n,3] on the GPU (nos_ndt_map_build, the reference's
         UpdateNdtMap).  → (NdtMap, stats dict with means, sqrt_infos, valid, counts, cells).
 
@@ -510,7 +510,10 @@ class NdtMap:
 
         reference_exact=True (NOS_MAP_REFERENCE_EXACT): the harness formula with the reference binary's rounding —
         sequential per-voxel accumulation, Eigen's SelfAdjointEigenSolver restated, the reference build's fused
-        multiply-adds; voxels in first-seen order; the stats dict also carries eigvals / eigvecs."""
+        multiply-adds; voxels in first-seen order; the stats dict also carries eigvals / eigvecs.
+
+        return_stats=False: out_stats = NULL — the voxel statistics never leave the device (the matcher's tables are
+        built there); → (NdtMap, None)."""
         pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
         h = ctypes.c_void_p()
         hs = ctypes.c_void_p()
@@ -518,8 +521,15 @@ class NdtMap:
         flags = 2 if reference_exact else int(bool(proper_sqrt_information))
         check(lib.nos_ndt_map_build(ctx.handle, pts.shape[0], _dp(pts), ctypes.c_double(voxel_resolution),
                                     ctypes.c_double(search_radius_sq), flags,
-                                    ctypes.byref(h), ctypes.byref(hs)),
+                                    ctypes.byref(h), ctypes.byref(hs) if return_stats else None),
               "nos_ndt_map_build")
+        if not return_stats:
+            self = cls.__new__(cls)
+            self._ctx = ctx
+            self._lib = lib
+            self._h = h
+            ctx._adopt(self)
+            return self, None
         V = int(lib.nos_map_stats_size(hs))
         means = np.zeros((V, 3))
         S = np.zeros((V, 9))

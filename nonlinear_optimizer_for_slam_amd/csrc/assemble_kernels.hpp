@@ -2240,6 +2240,10 @@ struct IndexedLayout {
   uint64_t n_padded;       // multiple of the kernel chunk; pads carry index -1
 };
 
+// Only the nine values in use are loaded (fp64: four 16-byte loads + one 8-byte, fp32: two 16-byte + one 4-byte).  A
+// wider last load would fetch a pad element into a register the compiler knows to be dead: it re-uses that register as a
+// temporary inside the item math while the load is still in flight, and the write-after-write hazard costs an
+// `s_waitcnt vmcnt(0)` in the middle of every evaluation (round 3's ISA) — i.e. the whole software pipeline.
 template <typename T>
 __device__ __forceinline__ void load_voxel_record(const T* table, int32_t v, T (&rec)[12]) {
   const T* p = table + size_t(16) * size_t(v);
@@ -2247,20 +2251,22 @@ __device__ __forceinline__ void load_voxel_record(const T* table, int32_t v, T (
     using V2 = double __attribute__((ext_vector_type(2)));
     const V2* q = reinterpret_cast<const V2*>(p);
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {  // mean (3) + A = SᵀS (6) = 9 values: five 16-byte loads
+    for (int k = 0; k < 4; ++k) {  // mean (3) + A = SᵀS (6) = 9 values
       const V2 t = q[k];
       rec[2 * k] = t[0];
       rec[2 * k + 1] = t[1];
     }
+    rec[8] = p[8];
   } else {
     using V4 = float __attribute__((ext_vector_type(4)));
     const V4* q = reinterpret_cast<const V4*>(p);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < 2; ++k) {
       const V4 t = q[k];
 #pragma unroll
       for (int m = 0; m < 4; ++m) rec[4 * k + m] = t[m];
     }
+    rec[8] = p[8];
   }
 }
 
@@ -2282,37 +2288,40 @@ __global__ __launch_bounds__(BLOCK, MINW) void assemble_indexed_kernel(IndexedLa
 #pragma unroll
   for (int k = 0; k < kOut; ++k) acc[k] = T(0);
 
+  // No load sits behind a branch: a chunk index past the end is clamped to the last chunk (its loads are issued and their
+  // results ignored — `live` below), because a branch around a load makes the compiler's wait-count bookkeeping fall back
+  // to `s_waitcnt vmcnt(0)` at the join, which serialised the three stages (round 3's ISA: six vmcnt(0) in the loop body).
+  const uint32_t last_chunk = n_chunks - 1u;
   auto load_point = [&](uint32_t c, T (&p)[3], int32_t (&vid)[K]) {
-    if (c < n_chunks) {
-      const uint64_t i = uint64_t(c) * BLOCK + threadIdx.x;
-      p[0] = __builtin_nontemporal_load(pts + i);
-      p[1] = __builtin_nontemporal_load(pts + L.n_padded + i);
-      p[2] = __builtin_nontemporal_load(pts + 2 * L.n_padded + i);
+    const uint64_t i = uint64_t(c < n_chunks ? c : last_chunk) * BLOCK + threadIdx.x;
+    p[0] = __builtin_nontemporal_load(pts + i);
+    p[1] = __builtin_nontemporal_load(pts + L.n_padded + i);
+    p[2] = __builtin_nontemporal_load(pts + 2 * L.n_padded + i);
 #pragma unroll
-      for (int k = 0; k < K; ++k) vid[k] = __builtin_nontemporal_load(L.index + uint64_t(k) * L.n_padded + i);
-    } else {
-      p[0] = p[1] = p[2] = T(0);
-#pragma unroll
-      for (int k = 0; k < K; ++k) vid[k] = -1;
-    }
+    for (int k = 0; k < K; ++k) vid[k] = __builtin_nontemporal_load(L.index + uint64_t(k) * L.n_padded + i);
   };
   auto load_records = [&](const int32_t (&vid)[K], T (&rec)[K][12]) {
 #pragma unroll
     for (int k = 0; k < K; ++k) load_voxel_record<T>(table, vid[k] < 0 ? 0 : vid[k], rec[k]);  // id 0 is always readable
   };
 
-  // Three-stage software pipeline, unrolled three times so that the buffers rotate by NAME instead of by register
-  // copies (a copy of a buffer that is still being loaded forces a wait, and the compiler's conservative waitcnt
-  // placement around loop-carried copies made every iteration wait for the loads it had just issued):
-  //   stage(A, B, C):  issue points+ids of chunk c+2g into C | issue the voxel records of chunk c+g (ids in B) |
-  //                    evaluate chunk c from A (points, ids, records all loaded one / two stages ago)
-  T pt0[3], pt1[3], pt2[3];
-  int32_t id0[K], id1[K], id2[K];
-  T rc0[K][12], rc1[K][12], rc2[K][12];
-  auto evaluate = [&](const T (&p)[3], const int32_t (&vid)[K], const T (&rec)[K][12]) {
+  // Software pipeline with two prefetch distances.  The point stream comes from HBM (28 bytes per lane and chunk): by
+  // Little's law its rate is (bytes in flight) / latency, and round 3's two chunks in flight — 28 KB per CU — were what held
+  // the kernel at 3.1 TB/s of its own bytes with the vector ALUs 26 % busy (profiles/r04pre_indexed_summary.json).  So the
+  // points and ids run kPointAhead chunks ahead of the evaluation (7 registers per chunk), the voxel records (L1 / L2
+  // hits: the points are sorted by voxel) one chunk ahead.  Buffers are rings indexed by stage number; the loop body is
+  // unrolled over one full rotation of both rings (kUnroll stages), so every index is a constant and the rings live in
+  // registers, rotating by NAME — no copies, and the compiler's wait counts stay exact (vmcnt(N), never vmcnt(0)).
+  // (fp32: 12 waves per CU, half the bytes per chunk — three chunks ahead; unroll = lcm of the two ring lengths)
+  constexpr int kPointAhead = sizeof(T) == 8 ? 4 : 3, kPointRing = kPointAhead + 1, kRecordRing = 2,
+                kUnroll = (kPointRing % kRecordRing == 0) ? kPointRing : kPointRing * kRecordRing;
+  T pt[kPointRing][3];
+  int32_t id[kPointRing][K];
+  T rc[kRecordRing][K][12];
+  auto evaluate = [&](bool live, const T (&p)[3], const int32_t (&vid)[K], const T (&rec)[K][12]) {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      if (vid[k] >= 0) {
+      if (live && vid[k] >= 0) {
         const T mu[3] = {rec[k][0], rec[k][1], rec[k][2]};
         const T A[6] = {rec[k][3], rec[k][4], rec[k][5], rec[k][6], rec[k][7], rec[k][8]};
         Problem::item_A(p, mu, A, P, acc);
@@ -2321,25 +2330,18 @@ __global__ __launch_bounds__(BLOCK, MINW) void assemble_indexed_kernel(IndexedLa
   };
   uint32_t c = blockIdx.x;
   const uint32_t g = gridDim.x;
-  load_point(c, pt0, id0);
-  load_point(c + g, pt1, id1);
-  load_records(id0, rc0);
-  for (; c < n_chunks; c += 3 * g) {
-    load_point(c + 2 * g, pt2, id2);
-    load_records(id1, rc1);
-    __builtin_amdgcn_sched_barrier(0);
-    evaluate(pt0, id0, rc0);
-    __builtin_amdgcn_sched_barrier(0);
-    load_point(c + 3 * g, pt0, id0);
-    load_records(id2, rc2);
-    __builtin_amdgcn_sched_barrier(0);
-    evaluate(pt1, id1, rc1);
-    __builtin_amdgcn_sched_barrier(0);
-    load_point(c + 4 * g, pt1, id1);
-    load_records(id0, rc0);
-    __builtin_amdgcn_sched_barrier(0);
-    evaluate(pt2, id2, rc2);
-    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int s = 0; s < kPointAhead; ++s) load_point(c + uint32_t(s) * g, pt[s], id[s]);
+  load_records(id[0], rc[0]);
+  for (; c < n_chunks; c += uint32_t(kUnroll) * g) {
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {  // stage u: chunk c + u g
+      load_point(c + uint32_t(u + kPointAhead) * g, pt[(u + kPointAhead) % kPointRing], id[(u + kPointAhead) % kPointRing]);
+      load_records(id[(u + 1) % kPointRing], rc[(u + 1) % kRecordRing]);
+      __builtin_amdgcn_sched_barrier(0);
+      evaluate(c + uint32_t(u) * g < n_chunks, pt[u % kPointRing], id[u % kPointRing], rc[u % kRecordRing]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
   double dacc[kOut];
 #pragma unroll

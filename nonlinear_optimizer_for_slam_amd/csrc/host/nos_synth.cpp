@@ -337,6 +337,36 @@ int nos_synth_pose_graph(uint64_t seed, size_t n, int extra_per_pose, double* po
 }
 
 // which: 0 = NDT scene, 1 = reprojection scene.  R row-major.
+// The room of the reference's NDT test drivers (MDM/tests/simple_optimization_test.cc:170-204, GenerateGlobalPoints): floor
+// and four walls of a 7 x 5 x 2.5 m box sampled at 1 cm, the loop variables accumulated in floating point exactly as there
+// (the captured runs under results/ depend on these very doubles).  Returns the number of points (954 605); writes at most
+// `capacity` of them as xyz triples.  Synthetic INPUT of tests and bench, like the generators above.
+size_t nos_synth_room_points(double* out, size_t capacity) {
+  const double width = 5.0, length = 7.0, height = 2.5, step = 0.01;
+  size_t n = 0;
+  auto push = [&](double a, double b, double c) {
+    if (out != nullptr && n < capacity) {
+      out[3 * n + 0] = a;
+      out[3 * n + 1] = b;
+      out[3 * n + 2] = c;
+    }
+    ++n;
+  };
+  for (double x = -length / 2.0; x <= length / 2.0; x += step)
+    for (double y = -width / 2.0; y <= width / 2.0; y += step) push(x, y, 0.0);
+  for (double x = -length / 2.0; x <= length / 2.0; x += step)
+    for (double z = 0.0; z <= height; z += step) {
+      push(x, -width / 2.0, z);
+      push(x, width / 2.0, z);
+    }
+  for (double y = -width / 2.0; y <= width / 2.0; y += step)
+    for (double z = 0.0; z <= height; z += step) {
+      push(length / 2.0, y, z);
+      push(-length / 2.0, y, z);
+    }
+  return n;
+}
+
 void nos_synth_true_pose(int which, double R[9], double t[3]) {
   if (which == 0)
     TruePoseNdt(R, t);

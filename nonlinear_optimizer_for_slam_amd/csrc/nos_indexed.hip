@@ -11,9 +11,9 @@ template <typename Problem, typename T, int K>
 int launch_indexed_kernel(const nos::IndexedLayout& L, const typename Problem::Params& P, int grid_cap, int num_cus,
                           double* partials, const nos::FusedFinal& fin_in, hipStream_t stream, int* rows_out) {
   // one large workgroup per CU, sized so that the hand-pipelined loop (two chunks of loads in flight next to
-  // the chunk being evaluated) stays in registers: fp64 8 waves (<= 256 VGPRs), fp32 16 waves (K = 1) / 12 (K = 2)
-  constexpr int kBlock = sizeof(T) == 8 ? 512 : (K == 1 ? 1024 : 768);
-  constexpr int kMinWaves = sizeof(T) == 8 ? 2 : (K == 1 ? 4 : 3);
+  // the chunk being evaluated) stays in registers: fp64 8 waves (<= 256 VGPRs), fp32 12 waves (<= 168)
+  constexpr int kBlock = sizeof(T) == 8 ? 512 : 768;
+  constexpr int kMinWaves = sizeof(T) == 8 ? 2 : 3;
   const uint64_t n_chunks64 = L.n_padded / kBlock;
   if (n_chunks64 > 0xFFFFFFFFull) return fail(NOS_ERR_UNSUPPORTED, "dataset too large for one shard");
   int grid = int(std::min<uint64_t>(std::max<uint64_t>(n_chunks64, 1), uint64_t(grid_cap)));

@@ -309,6 +309,9 @@ int dataset_new(nos_ctx* ctx, int kind, size_t n, int dtype, nos_dataset** out, 
 int zero_pad(int dtype, int n_fields, const nos::TiledLayout& L, void* dst, hipStream_t stream);
 int unpack_records(int dtype, const unsigned char* d_rec, size_t stride, const nos::FieldOffsets& fo, int n_fields,
                    size_t first, size_t count, const nos::TiledLayout& L, void* dst, hipStream_t stream);
+// nos_match.hip: matcher tables from device-resident voxel statistics (valid may be null = all valid)
+int map_create_device(nos_ctx* ctx, size_t n_voxels, const double* d_means, const double* d_S, const unsigned char* d_valid,
+                      double search_radius_sq, nos_ndt_map** out_map);
 // nos_indexed.hip
 int launch_indexed(const nos_dataset* ds, const Shard& sh, const Request& rq, double* partials,
                    const nos::FusedFinal& fin, hipStream_t stream, int* rows_out);

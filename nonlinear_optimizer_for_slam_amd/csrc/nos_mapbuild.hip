@@ -208,21 +208,25 @@ int nos_ndt_map_build(nos_ctx* ctx, size_t n_points, const double* points_xyz, d
                        prm, d_mean, d_S, d_valid);
     e = hipGetLastError();
   }
-  std::vector<uint64_t> h_keys(V);
+  // The statistics stay on the device for the matcher's tables (map_create_device: bucketing by matcher cell, dense grid
+  // and hash table are built there); they travel to the host only for the caller's nos_map_stats and for the reference-exact
+  // mode, whose voxel list is re-ordered to first-seen order before the tables are built.
+  const bool want_stats = out_stats != nullptr || exact;
+  std::vector<uint64_t> h_keys(want_stats ? V : 0);
   std::vector<uint32_t> h_first;
   if (e == hipSuccess && exact) {
     stats->evals.resize(size_t(V) * 3);
     stats->evecs.resize(size_t(V) * 9);
     h_first.resize(V);
   }
-  if (e == hipSuccess) {
+  if (e == hipSuccess && want_stats) {
     stats->means.resize(size_t(V) * 3);
     stats->sqrt_infos.resize(size_t(V) * 9);
     stats->valid.resize(V);
     stats->counts.resize(V);
     stats->cells.resize(size_t(V) * 3);
   }
-  if (e == hipSuccess && V > 0) {
+  if (e == hipSuccess && V > 0 && want_stats) {
     e = hipMemcpyAsync(stats->means.data(), d_mean, size_t(V) * 3 * sizeof(double), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipMemcpyAsync(stats->sqrt_infos.data(), d_S, size_t(V) * 9 * sizeof(double), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipMemcpyAsync(stats->valid.data(), d_valid, V, hipMemcpyDeviceToHost, st);
@@ -233,13 +237,20 @@ int nos_ndt_map_build(nos_ctx* ctx, size_t n_points, const double* points_xyz, d
       if (e == hipSuccess) e = hipMemcpyAsync(stats->evecs.data(), d_evecs, size_t(V) * 9 * sizeof(double), hipMemcpyDeviceToHost, st);
       if (e == hipSuccess) e = hipMemcpyAsync(h_first.data(), d_first, size_t(V) * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e == hipSuccess && !exact) {  // tables straight from the device-resident statistics
+    rc = map_create_device(ctx, V, d_mean, d_S, d_valid, search_radius_sq, out_map);
+    if (rc != NOS_OK) {
+      nos_scan_destroy(scan);
+      return rc;
+    }
   }
   nos_scan_destroy(scan);
   if (e != hipSuccess)
     return fail(e == hipErrorOutOfMemory ? NOS_ERR_OUT_OF_MEMORY : NOS_ERR_HIP, "map build failed: %s", hipGetErrorString(e));
   const int64_t bias = int64_t(1) << 20;
-  for (uint32_t v = 0; v < V; ++v) {
+  for (uint32_t v = 0; v < V && want_stats; ++v) {
     stats->cells[3 * size_t(v) + 0] = int64_t((h_keys[v] >> 42) & 0x1FFFFFull) - bias;
     stats->cells[3 * size_t(v) + 1] = int64_t((h_keys[v] >> 21) & 0x1FFFFFull) - bias;
     stats->cells[3 * size_t(v) + 2] = int64_t(h_keys[v] & 0x1FFFFFull) - bias;
@@ -263,9 +274,11 @@ int nos_ndt_map_build(nos_ctx* ctx, size_t n_points, const double* points_xyz, d
     permute(stats->evals, 3);
     permute(stats->evecs, 9);
   }
-  rc = nos_ndt_map_create(ctx, V, stats->means.data(), stats->sqrt_infos.data(), stats->valid.data(), search_radius_sq,
-                          out_map);
-  if (rc != NOS_OK) return rc;
+  if (exact) {
+    rc = nos_ndt_map_create(ctx, V, stats->means.data(), stats->sqrt_infos.data(), stats->valid.data(), search_radius_sq,
+                            out_map);
+    if (rc != NOS_OK) return rc;
+  }
   if (out_stats) *out_stats = stats.release();
   return NOS_OK;
 }

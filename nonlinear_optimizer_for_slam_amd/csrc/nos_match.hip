@@ -1,134 +1,256 @@
 // nos_match.hip — device correspondence matcher, scans, dataset download.
 #include "nos_internal.hpp"
 
+#include <rocprim/rocprim.hpp>
+
 using namespace nosd;
 
-extern "C" {
+namespace {
 
-int nos_ndt_map_create(nos_ctx* ctx, size_t n_voxels, const double* means_xyz, const double* sqrt_infos,
-                       const unsigned char* valid, double search_radius_sq, nos_ndt_map** out_map) {
-  nosd::CtxGuard guard_(ctx);  // one solve / accumulate / create at a time per context
-  if (!ctx || !out_map) return fail(NOS_ERR_INVALID_ARGUMENT, "ctx / out_map is NULL");
-  *out_map = nullptr;
-  if (ctx->slots.size() != 1) return fail(NOS_ERR_UNSUPPORTED, "the matcher needs a single-device context");
-  if ((!means_xyz || !sqrt_infos) && n_voxels > 0) return fail(NOS_ERR_INVALID_ARGUMENT, "map arrays are NULL");
-  if (!(search_radius_sq > 0.0) || !std::isfinite(search_radius_sq)) return fail(NOS_ERR_INVALID_ARGUMENT, "bad search radius");
-  if (n_voxels >= 0xFFFFFFFFull) return fail(NOS_ERR_UNSUPPORTED, "too many voxels");
-  const double cell = std::sqrt(search_radius_sq);
-  const double inv_cell = 1.0 / cell;
-  // bucket the valid voxels by grid cell: sort (cell key, voxel index) pairs — cells in key order, voxels of a cell in
-  // index order (deterministic layout; a sorted vector instead of a std::map of vectors: 5-10x less host time at 10^5+ voxels)
-  std::vector<std::pair<uint64_t, uint32_t>> keyed;
-  keyed.reserve(n_voxels);
-  for (size_t v = 0; v < n_voxels; ++v) {
-    if (valid && !valid[v]) continue;  // `if (!ndt.is_valid) continue;` of the reference's matcher
-    const double* m = means_xyz + 3 * v;
-    if (!std::isfinite(m[0]) || !std::isfinite(m[1]) || !std::isfinite(m[2]))
-      return fail(NOS_ERR_INVALID_ARGUMENT, "voxel %zu has a non-finite mean", v);
-    const int64_t ix = int64_t(std::floor(m[0] * inv_cell)), iy = int64_t(std::floor(m[1] * inv_cell)),
-                  iz = int64_t(std::floor(m[2] * inv_cell));
-    const int64_t lim = (1 << 20) - 2;
-    if (std::llabs(ix) > lim || std::llabs(iy) > lim || std::llabs(iz) > lim)
-      return fail(NOS_ERR_UNSUPPORTED, "voxel %zu lies outside the addressable grid", v);
-    keyed.emplace_back(nos::pack_cell(ix, iy, iz), uint32_t(v));
+// ---- matcher tables built on the device (round 4; the host used to sort (cell, voxel) pairs, walk the runs and fill the
+// hash table and the dense grid: 50-70 ms at 8·10^5 voxels, behind a download of the voxel statistics and in front of an
+// upload of the re-ordered copies).  Same layout as before: records in ascending (cell key, voxel index) order — a stable
+// radix sort of (key, index) pairs —, dense offsets = exclusive prefix sums of the per-cell counts, and an open-addressing
+// table cell key → (first record, count).  The dense form and the record order are unique, hence bit-identical to the host
+// construction; the hash table's slot assignment depends on the order in which colliding cells arrive (atomic compare-and-
+// swap), which no lookup can observe: a probe sequence ends at the key or at a free slot either way.
+
+constexpr int64_t kCellLimit = (1 << 20) - 2;
+
+// flags[0] != 0: a valid voxel with a non-finite mean (flags[1] = its index + 1); flags[2] != 0: outside the addressable grid
+__global__ __launch_bounds__(256) void map_cell_key_kernel(const double* __restrict__ means, const unsigned char* __restrict__ valid,
+                                                           uint32_t n_voxels, double inv_cell, uint64_t* __restrict__ keys,
+                                                           uint32_t* __restrict__ idx, unsigned int* __restrict__ flags) {
+  const uint32_t v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= n_voxels) return;
+  idx[v] = v;
+  if (valid != nullptr && !valid[v]) {  // `if (!ndt.is_valid) continue;` of the reference's matcher
+    keys[v] = nos::kEmptyCell;          // sorts behind every cell
+    return;
   }
-  std::sort(keyed.begin(), keyed.end());
-  struct CellRun {
-    uint64_t key;
-    uint32_t first, count;  // range of `keyed`
-  };
-  std::vector<CellRun> cells;
-  for (size_t i = 0; i < keyed.size();) {
-    size_t j = i;
-    while (j < keyed.size() && keyed[j].first == keyed[i].first) ++j;
-    cells.push_back({keyed[i].first, uint32_t(i), uint32_t(j - i)});
-    i = j;
+  const double x = means[3 * size_t(v)], y = means[3 * size_t(v) + 1], z = means[3 * size_t(v) + 2];
+  if (!(isfinite(x) && isfinite(y) && isfinite(z))) {
+    if (atomicCAS(&flags[0], 0u, 1u) == 0u) flags[1] = v + 1u;
+    keys[v] = nos::kEmptyCell;
+    return;
   }
-  size_t table_size = 16;
-  while (table_size < 2 * cells.size() + 1) table_size <<= 1;
-  std::vector<uint64_t> keys(table_size, nos::kEmptyCell);
-  std::vector<uint32_t> starts(table_size, 0), counts(table_size, 0), orig;
-  std::vector<double> mean_sorted, s_sorted;
-  orig.reserve(keyed.size());
-  mean_sorted.reserve(keyed.size() * 3);
-  s_sorted.reserve(keyed.size() * 9);
-  for (const CellRun& cr : cells) {
-    uint32_t h = nos::hash_cell(cr.key) & uint32_t(table_size - 1);
-    while (keys[h] != nos::kEmptyCell) h = (h + 1) & uint32_t(table_size - 1);
-    keys[h] = cr.key;
-    starts[h] = uint32_t(orig.size());
-    counts[h] = cr.count;
-    for (uint32_t q = cr.first; q < cr.first + cr.count; ++q) {
-      const uint32_t v = keyed[q].second;
-      orig.push_back(v);
-      for (int k = 0; k < 3; ++k) mean_sorted.push_back(means_xyz[3 * size_t(v) + k]);
-      for (int k = 0; k < 9; ++k) s_sorted.push_back(sqrt_infos[9 * size_t(v) + k]);
+  const int64_t ix = int64_t(floor(x * inv_cell)), iy = int64_t(floor(y * inv_cell)), iz = int64_t(floor(z * inv_cell));
+  if (llabs(ix) > kCellLimit || llabs(iy) > kCellLimit || llabs(iz) > kCellLimit) {
+    if (atomicCAS(&flags[2], 0u, 1u) == 0u) flags[3] = v + 1u;
+    keys[v] = nos::kEmptyCell;
+    return;
+  }
+  keys[v] = nos::pack_cell(ix, iy, iz);
+}
+
+// records in cell order: mean [V][3], sqrt-information [V][9], candidate records [V][4] = {mean, original id bits}
+__global__ __launch_bounds__(256) void map_gather_kernel(const double* __restrict__ means, const double* __restrict__ sqrt_infos,
+                                                         const uint32_t* __restrict__ orig, uint32_t n_valid,
+                                                         double* __restrict__ mean_sorted, double* __restrict__ s_sorted,
+                                                         double* __restrict__ records) {
+  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n_valid) return;
+  const uint32_t v = orig[j];
+  double m[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    m[k] = means[3 * size_t(v) + k];
+    mean_sorted[3 * size_t(j) + k] = m[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) s_sorted[9 * size_t(j) + k] = sqrt_infos[9 * size_t(v) + k];
+  if (records != nullptr) {
+    records[4 * size_t(j)] = m[0];
+    records[4 * size_t(j) + 1] = m[1];
+    records[4 * size_t(j) + 2] = m[2];
+    records[4 * size_t(j) + 3] = __longlong_as_double((long long)(unsigned long long)v);
+  }
+}
+
+// bounding box of the occupied cells: box[0..2] = min, box[3..5] = max (biased coordinates, 21 bits each)
+__global__ __launch_bounds__(256) void map_cell_box_kernel(const uint64_t* __restrict__ cell_keys, uint32_t n_cells,
+                                                           unsigned int* __restrict__ box) {
+  const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+  unsigned int lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
+  if (c < n_cells) {
+    const uint64_t key = cell_keys[c];
+    lo[0] = hi[0] = unsigned((key >> 42) & 0x1FFFFFull);
+    lo[1] = hi[1] = unsigned((key >> 21) & 0x1FFFFFull);
+    lo[2] = hi[2] = unsigned(key & 0x1FFFFFull);
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    unsigned a = lo[k], b = hi[k];
+#pragma unroll
+    for (int o = nos::kWave / 2; o > 0; o >>= 1) {
+      a = min(a, unsigned(__shfl_xor(int(a), o, nos::kWave)));
+      b = max(b, unsigned(__shfl_xor(int(b), o, nos::kWave)));
+    }
+    if ((threadIdx.x & (nos::kWave - 1)) == 0 && a != 0xFFFFFFFFu) {
+      atomicMin(&box[k], a);
+      atomicMax(&box[3 + k], b);
     }
   }
-  // dense form of the grid (see MapView): bounding box of the occupied cells plus a one-cell border
-  std::vector<uint32_t> dense_begin;
-  std::vector<double> records;
-  int64_t lo[3] = {0, 0, 0}, dim[3] = {0, 0, 0};
-  if (!cells.empty() && ctx->settings.match_dense != 0) {
+}
+
+// hash table cell key → (first record, count), and the dense grid's per-cell counts (dense_begin[idx + 1] = count)
+__global__ __launch_bounds__(256) void map_cell_tables_kernel(const uint64_t* __restrict__ cell_keys,
+                                                              const uint32_t* __restrict__ cell_counts,
+                                                              const uint32_t* __restrict__ cell_starts, uint32_t n_cells,
+                                                              uint32_t table_mask, unsigned long long* __restrict__ tab_key,
+                                                              uint32_t* __restrict__ tab_start, uint32_t* __restrict__ tab_count,
+                                                              uint32_t* __restrict__ dense_begin, int64_t ox, int64_t oy, int64_t oz,
+                                                              int64_t ny, int64_t nz) {
+  const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= n_cells) return;
+  const uint64_t key = cell_keys[c];
+  uint32_t h = nos::hash_cell(key) & table_mask;
+  for (;;) {  // the table is at most half full: a free slot always turns up
+    const unsigned long long seen = atomicCAS(&tab_key[h], (unsigned long long)nos::kEmptyCell, (unsigned long long)key);
+    if (seen == nos::kEmptyCell) break;
+    h = (h + 1) & table_mask;
+  }
+  tab_start[h] = cell_starts[c];
+  tab_count[h] = cell_counts[c];
+  if (dense_begin != nullptr) {
     const int64_t bias = int64_t(1) << 20;
-    int64_t mn[3] = {INT64_MAX, INT64_MAX, INT64_MAX}, mx[3] = {INT64_MIN, INT64_MIN, INT64_MIN};
-    auto unpack = [&](uint64_t key, int64_t c[3]) {
-      c[0] = int64_t((key >> 42) & 0x1FFFFFull) - bias;
-      c[1] = int64_t((key >> 21) & 0x1FFFFFull) - bias;
-      c[2] = int64_t(key & 0x1FFFFFull) - bias;
-    };
-    for (const CellRun& cr : cells) {
-      int64_t c[3];
-      unpack(cr.key, c);
-      for (int k = 0; k < 3; ++k) {
-        mn[k] = std::min(mn[k], c[k]);
-        mx[k] = std::max(mx[k], c[k]);
-      }
-    }
-    double total = 1.0;
-    for (int k = 0; k < 3; ++k) {
-      lo[k] = mn[k] - 1;
-      dim[k] = mx[k] - mn[k] + 3;
-      total *= double(dim[k]);
-    }
-    if (total <= double(size_t(1) << 26)) {  // ≤ 64 M cells = 256 MB of offsets; beyond that the hash table serves
-      const size_t n_cells = size_t(dim[0]) * size_t(dim[1]) * size_t(dim[2]);
-      dense_begin.assign(n_cells + 1, 0);
-      // ascending packed keys = (x, y, z) lexicographic order = dense index order = record order
-      for (const CellRun& cr : cells) {
-        int64_t c[3];
-        unpack(cr.key, c);
-        const size_t idx = (size_t(c[0] - lo[0]) * size_t(dim[1]) + size_t(c[1] - lo[1])) * size_t(dim[2]) + size_t(c[2] - lo[2]);
-        dense_begin[idx + 1] = cr.count;
-      }
-      for (size_t c = 0; c < n_cells; ++c) dense_begin[c + 1] += dense_begin[c];
-      records.resize(orig.size() * 4);
-      for (size_t j = 0; j < orig.size(); ++j) {
-        for (int k = 0; k < 3; ++k) records[4 * j + k] = mean_sorted[3 * j + k];
-        const uint64_t bits = orig[j];
-        memcpy(&records[4 * j + 3], &bits, sizeof(double));
-      }
-    }
+    const int64_t cx = int64_t((key >> 42) & 0x1FFFFFull) - bias, cy = int64_t((key >> 21) & 0x1FFFFFull) - bias,
+                  cz = int64_t(key & 0x1FFFFFull) - bias;
+    const size_t idx = (size_t(cx - ox) * size_t(ny) + size_t(cy - oy)) * size_t(nz) + size_t(cz - oz);
+    dense_begin[idx + 1] = cell_counts[c];
   }
+}
+
+// Builds the map object from DEVICE arrays of voxel statistics (means [V][3], sqrt-informations [V][9], valid [V] or null).
+int map_create_from_device(nos_ctx* ctx, size_t n_voxels, const double* d_means, const double* d_S, const unsigned char* d_valid,
+                           double search_radius_sq, nos_ndt_map** out_map) {
+  const double inv_cell = 1.0 / std::sqrt(search_radius_sq);
+  DeviceSlot& slot = ctx->slots[0];
+  hipStream_t st = slot.stream;
+  const uint32_t V = uint32_t(n_voxels);
   nos_ndt_map* map = new (std::nothrow) nos_ndt_map();
   if (!map) return fail(NOS_ERR_OUT_OF_MEMORY, "host allocation failed");
   map->ctx = ctx;
-  map->n_voxels = orig.size();
-  hipError_t e = hipSetDevice(ctx->slots[0].device);
-  if (e == hipSuccess) e = upload(&map->d_mean, mean_sorted);
-  if (e == hipSuccess) e = upload(&map->d_sqrt_info, s_sorted);
-  if (e == hipSuccess) e = upload(&map->d_orig_id, orig);
-  if (e == hipSuccess) e = upload(&map->d_cell_key, keys);
-  if (e == hipSuccess) e = upload(&map->d_cell_start, starts);
-  if (e == hipSuccess) e = upload(&map->d_cell_count, counts);
+  DeviceBuffers buf;
+  uint64_t *keys = nullptr, *keys_sorted = nullptr, *uniq = nullptr;
+  uint32_t *idx = nullptr, *run_count = nullptr, *run_start = nullptr, *n_runs = nullptr;
+  unsigned int *flags = nullptr, *box = nullptr;
+  hipError_t e = hipSetDevice(slot.device);
+  const size_t cap = std::max<size_t>(V, 1);
+  if (e == hipSuccess) e = buf.alloc(&keys, cap);
+  if (e == hipSuccess) e = buf.alloc(&keys_sorted, cap);
+  if (e == hipSuccess) e = buf.alloc(&uniq, cap);
+  if (e == hipSuccess) e = buf.alloc(&idx, cap);
+  if (e == hipSuccess) e = buf.alloc(&run_count, cap);
+  if (e == hipSuccess) e = buf.alloc(&run_start, cap);
+  if (e == hipSuccess) e = buf.alloc(&n_runs, 1);
+  if (e == hipSuccess) e = buf.alloc(&flags, 4);
+  if (e == hipSuccess) e = buf.alloc(&box, 6);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&map->d_orig_id), cap * sizeof(uint32_t));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&map->d_n_matches), sizeof(unsigned long long));
-  if (e == hipSuccess && !dense_begin.empty()) {
-    e = upload(&map->d_dense_begin, dense_begin);
-    if (e == hipSuccess) e = upload(&map->d_record, records);
+  uint32_t runs = 0, n_cells = 0, n_valid = 0;
+  unsigned int h_flags[4] = {0, 0, 0, 0}, h_box[6] = {0, 0, 0, 0, 0, 0};
+  size_t t_sort = 0, t_rle = 0, t_scan = 0;
+  void* tmp = nullptr;
+  if (e == hipSuccess && V > 0) {
+    const unsigned int box_init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
+    e = hipMemsetAsync(flags, 0, 4 * sizeof(unsigned int), st);
+    if (e == hipSuccess) e = hipMemcpyAsync(box, box_init, sizeof box_init, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(map_cell_key_kernel, dim3((V + 255) / 256), dim3(256), 0, st, d_means, d_valid, V, inv_cell, keys, idx,
+                         flags);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = rocprim::radix_sort_pairs(nullptr, t_sort, keys, keys_sorted, idx, map->d_orig_id, size_t(V), 0, 64, st);
+    if (e == hipSuccess) e = rocprim::run_length_encode(nullptr, t_rle, keys_sorted, size_t(V), uniq, run_count, n_runs, st);
+    if (e == hipSuccess) e = rocprim::exclusive_scan(nullptr, t_scan, run_count, run_start, 0u, size_t(V), rocprim::plus<uint32_t>(), st);
+    if (e == hipSuccess) e = hipMalloc(&tmp, std::max(std::max(t_sort, t_rle), std::max(t_scan, size_t(16))));
+    if (e == hipSuccess) buf.ptrs.push_back(tmp);
+    // stable: the voxels of a cell stay in index order, as std::sort on (key, index) pairs left them
+    if (e == hipSuccess) e = rocprim::radix_sort_pairs(tmp, t_sort, keys, keys_sorted, idx, map->d_orig_id, size_t(V), 0, 64, st);
+    if (e == hipSuccess) e = rocprim::run_length_encode(tmp, t_rle, keys_sorted, size_t(V), uniq, run_count, n_runs, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(&runs, n_runs, sizeof runs, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(h_flags, flags, sizeof h_flags, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess && h_flags[0] != 0) {
+      nos_ndt_map_destroy(map);
+      return fail(NOS_ERR_INVALID_ARGUMENT, "voxel %u has a non-finite mean", h_flags[1] - 1u);
+    }
+    if (e == hipSuccess && h_flags[2] != 0) {
+      nos_ndt_map_destroy(map);
+      return fail(NOS_ERR_UNSUPPORTED, "voxel %u lies outside the addressable grid", h_flags[3] - 1u);
+    }
+    if (e == hipSuccess && runs > 0) {
+      // the invalid voxels, if any, form the last run (key = all ones)
+      uint64_t last_key = 0;
+      uint32_t last_count = 0;
+      e = hipMemcpyAsync(&last_key, uniq + (runs - 1), sizeof last_key, hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess) e = hipMemcpyAsync(&last_count, run_count + (runs - 1), sizeof last_count, hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess) e = rocprim::exclusive_scan(tmp, t_scan, run_count, run_start, 0u, size_t(runs), rocprim::plus<uint32_t>(), st);
+      if (e == hipSuccess) e = hipStreamSynchronize(st);
+      const bool has_invalid = last_key == nos::kEmptyCell;
+      n_cells = has_invalid ? runs - 1 : runs;
+      n_valid = has_invalid ? V - last_count : V;
+    }
+    if (e == hipSuccess && n_cells > 0) {
+      hipLaunchKernelGGL(map_cell_box_kernel, dim3((n_cells + 255) / 256), dim3(256), 0, st, uniq, n_cells, box);
+      e = hipGetLastError();
+      if (e == hipSuccess) e = hipMemcpyAsync(h_box, box, sizeof h_box, hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
   }
+  map->n_voxels = n_valid;
+  // dense form of the grid (see MapView): bounding box of the occupied cells plus a one-cell border
+  int64_t lo[3] = {0, 0, 0}, dim[3] = {0, 0, 0};
+  size_t n_dense = 0;
+  if (e == hipSuccess && n_cells > 0 && ctx->settings.match_dense != 0) {
+    const int64_t bias = int64_t(1) << 20;
+    double total = 1.0;
+    for (int k = 0; k < 3; ++k) {
+      lo[k] = int64_t(h_box[k]) - bias - 1;
+      dim[k] = int64_t(h_box[3 + k]) - int64_t(h_box[k]) + 3;
+      total *= double(dim[k]);
+    }
+    if (total <= double(size_t(1) << 26))  // ≤ 64 M cells = 256 MB of offsets; beyond that the hash table serves
+      n_dense = size_t(dim[0]) * size_t(dim[1]) * size_t(dim[2]);
+  }
+  size_t table_size = 16;
+  while (table_size < 2 * size_t(n_cells) + 1) table_size <<= 1;
+  const size_t nv = std::max<size_t>(n_valid, 1);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&map->d_mean), nv * 3 * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&map->d_sqrt_info), nv * 9 * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&map->d_cell_key), table_size * sizeof(uint64_t));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&map->d_cell_start), table_size * sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&map->d_cell_count), table_size * sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMemsetAsync(map->d_cell_key, 0xFF, table_size * sizeof(uint64_t), st);  // kEmptyCell
+  if (e == hipSuccess) e = hipMemsetAsync(map->d_cell_start, 0, table_size * sizeof(uint32_t), st);
+  if (e == hipSuccess) e = hipMemsetAsync(map->d_cell_count, 0, table_size * sizeof(uint32_t), st);
+  if (e == hipSuccess && n_dense > 0) {
+    e = hipMalloc(reinterpret_cast<void**>(&map->d_dense_begin), (n_dense + 1) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemsetAsync(map->d_dense_begin, 0, (n_dense + 1) * sizeof(uint32_t), st);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&map->d_record), nv * 4 * sizeof(double));
+  }
+  if (e == hipSuccess && n_valid > 0) {
+    hipLaunchKernelGGL(map_gather_kernel, dim3((n_valid + 255) / 256), dim3(256), 0, st, d_means, d_S, map->d_orig_id, n_valid,
+                       map->d_mean, map->d_sqrt_info, map->d_record);
+    hipLaunchKernelGGL(map_cell_tables_kernel, dim3((n_cells + 255) / 256), dim3(256), 0, st, uniq, run_count, run_start, n_cells,
+                       uint32_t(table_size - 1), reinterpret_cast<unsigned long long*>(map->d_cell_key), map->d_cell_start,
+                       map->d_cell_count, map->d_dense_begin, lo[0], lo[1], lo[2], dim[1], dim[2]);
+    e = hipGetLastError();
+    if (e == hipSuccess && n_dense > 0) {
+      size_t t_inc = 0;
+      void* tmp2 = nullptr;
+      e = rocprim::inclusive_scan(nullptr, t_inc, map->d_dense_begin, map->d_dense_begin, n_dense + 1, rocprim::plus<uint32_t>(), st);
+      if (e == hipSuccess) e = hipMalloc(&tmp2, std::max<size_t>(t_inc, 16));
+      if (e == hipSuccess) buf.ptrs.push_back(tmp2);
+      if (e == hipSuccess)
+        e = rocprim::inclusive_scan(tmp2, t_inc, map->d_dense_begin, map->d_dense_begin, n_dense + 1, rocprim::plus<uint32_t>(), st);
+    }
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(st);  // the temporaries go out of scope
   if (e != hipSuccess) {
     nos_ndt_map_destroy(map);
-    return fail(e == hipErrorOutOfMemory ? NOS_ERR_OUT_OF_MEMORY : NOS_ERR_HIP, "map upload failed: %s", hipGetErrorString(e));
+    return fail(e == hipErrorOutOfMemory ? NOS_ERR_OUT_OF_MEMORY : NOS_ERR_HIP, "map tables failed: %s", hipGetErrorString(e));
   }
   map->view.mean = map->d_mean;
   map->view.sqrt_info = map->d_sqrt_info;
@@ -149,6 +271,45 @@ int nos_ndt_map_create(nos_ctx* ctx, size_t n_voxels, const double* means_xyz, c
   map->view.nz = int32_t(dim[2]);
   *out_map = map;
   return NOS_OK;
+}
+
+}  // namespace
+
+// nos_mapbuild.hip: the voxel statistics are already on the device
+int nosd::map_create_device(nos_ctx* ctx, size_t n_voxels, const double* d_means, const double* d_S, const unsigned char* d_valid,
+                            double search_radius_sq, nos_ndt_map** out_map) {
+  return map_create_from_device(ctx, n_voxels, d_means, d_S, d_valid, search_radius_sq, out_map);
+}
+
+extern "C" {
+
+int nos_ndt_map_create(nos_ctx* ctx, size_t n_voxels, const double* means_xyz, const double* sqrt_infos,
+                       const unsigned char* valid, double search_radius_sq, nos_ndt_map** out_map) {
+  nosd::CtxGuard guard_(ctx);  // one solve / accumulate / create at a time per context
+  if (!ctx || !out_map) return fail(NOS_ERR_INVALID_ARGUMENT, "ctx / out_map is NULL");
+  *out_map = nullptr;
+  if (ctx->slots.size() != 1) return fail(NOS_ERR_UNSUPPORTED, "the matcher needs a single-device context");
+  if ((!means_xyz || !sqrt_infos) && n_voxels > 0) return fail(NOS_ERR_INVALID_ARGUMENT, "map arrays are NULL");
+  if (!(search_radius_sq > 0.0) || !std::isfinite(search_radius_sq)) return fail(NOS_ERR_INVALID_ARGUMENT, "bad search radius");
+  if (n_voxels >= 0xFFFFFFFFull) return fail(NOS_ERR_UNSUPPORTED, "too many voxels");
+  // the voxel statistics go to the device as they are; bucketing by matcher cell, the hash table and the dense grid are
+  // built there (map_create_from_device)
+  DeviceSlot& slot = ctx->slots[0];
+  DeviceBuffers buf;
+  double *d_means = nullptr, *d_S = nullptr;
+  unsigned char* d_valid = nullptr;
+  hipError_t e = hipSetDevice(slot.device);
+  if (e == hipSuccess) e = buf.alloc(&d_means, n_voxels * 3);
+  if (e == hipSuccess) e = buf.alloc(&d_S, n_voxels * 9);
+  if (e == hipSuccess && valid) e = buf.alloc(&d_valid, n_voxels);
+  if (e == hipSuccess && n_voxels > 0) {
+    e = hipMemcpyAsync(d_means, means_xyz, n_voxels * 3 * sizeof(double), hipMemcpyHostToDevice, slot.stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_S, sqrt_infos, n_voxels * 9 * sizeof(double), hipMemcpyHostToDevice, slot.stream);
+    if (e == hipSuccess && valid) e = hipMemcpyAsync(d_valid, valid, n_voxels, hipMemcpyHostToDevice, slot.stream);
+  }
+  if (e != hipSuccess)
+    return fail(e == hipErrorOutOfMemory ? NOS_ERR_OUT_OF_MEMORY : NOS_ERR_HIP, "map upload failed: %s", hipGetErrorString(e));
+  return map_create_from_device(ctx, n_voxels, d_means, d_S, d_valid, search_radius_sq, out_map);
 }
 
 int nos_ndt_map_destroy(nos_ndt_map* map) {

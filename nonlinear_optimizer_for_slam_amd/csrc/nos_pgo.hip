@@ -22,6 +22,7 @@ struct nos_pose_graph {
   double* d_hs = nullptr;                         // switch curvature
   double *d_grad = nullptr, *d_x = nullptr, *d_r = nullptr, *d_z = nullptr, *d_p = nullptr, *d_ap = nullptr;
   double *d_partials = nullptr, *d_scalars = nullptr;
+  unsigned int* d_tickets = nullptr;  // [2] arrival counters of the in-launch tails (product, preconditioner); zero between launches
   double* h_scalars = nullptr;  // pinned [4]
   uint32_t partial_blocks = 0;
   nos::PgoView view{};
@@ -150,23 +151,48 @@ int pgo_coarse_setup(nos_pose_graph* pg, double lambda, uint32_t agg) {
   return NOS_OK;
 }
 
+// Right-hand side in c_b[0] → xc = A_c^-1 rhs; returns the buffer holding xc.  The ⌈log2 n_agg⌉ PCR levels run in
+// spans of up to 7 levels per launch (pgo_pcr_span_kernel): at 1 M poses / 20 834 aggregates two launches — levels 0-6 with
+// halos, then levels 7-14 and the block solves inside one workgroup per residue class — instead of 16.
+int pgo_pcr_rhs(nos_pose_graph* pg, const double** xc) {
+  DeviceSlot& slot = pg->ctx->slots[0];
+  const uint32_t C = pg->n_agg, L = pg->pcr_levels;
+  constexpr uint32_t kSpanLevels = 7, kT = 512;
+  int cur = 0;
+  uint32_t l = 0;
+  for (;;) {
+    const uint32_t rows = uint32_t((uint64_t(C) + (1ull << l) - 1) >> l);  // rows of the largest residue class
+    const double* a = pg->c_alpha;
+    const double* g = pg->c_gamma;
+    if (rows <= kT) {  // the rest of the levels and the block solves, one workgroup per class
+      if (rows <= 256)
+        hipLaunchKernelGGL(nos::pgo_pcr_span_kernel<256>, dim3(1u << l), dim3(256), 0, slot.stream, C, l, L, 0u, a, g,
+                           pg->c_Dinv, pg->c_b[cur], pg->c_b[1 - cur]);
+      else
+        hipLaunchKernelGGL(nos::pgo_pcr_span_kernel<512>, dim3(1u << l), dim3(512), 0, slot.stream, C, l, L, 0u, a, g,
+                           pg->c_Dinv, pg->c_b[cur], pg->c_b[1 - cur]);
+      cur = 1 - cur;
+      break;
+    }
+    const uint32_t k = std::min(kSpanLevels, L - l), halo = (1u << k) - 1u, per = kT - 2 * halo;
+    const uint32_t chunks = (rows + per - 1) / per;
+    hipLaunchKernelGGL(nos::pgo_pcr_span_kernel<512>, dim3(chunks << l), dim3(512), 0, slot.stream, C, l, l + k, halo, a, g,
+                       static_cast<const double*>(nullptr), pg->c_b[cur], pg->c_b[1 - cur]);
+    cur = 1 - cur;
+    l += k;
+  }
+  NOS_HIP_CHECK(hipGetLastError());
+  *xc = pg->c_b[cur];
+  return NOS_OK;
+}
+
 // xc = A_c^-1 P^T r  →  returns the buffer holding xc.
 int pgo_coarse_apply(nos_pose_graph* pg, const double* r, const double** xc) {
   DeviceSlot& slot = pg->ctx->slots[0];
-  const uint32_t C = pg->n_agg, cblocks = (C + 127) / 128;
+  const uint32_t C = pg->n_agg;
   hipLaunchKernelGGL(nos::pgo_coarse_restrict_kernel, dim3((C + 3) / 4), dim3(256), 0, slot.stream, pg->view, pg->agg, C, r,
                      pg->c_b[0]);
-  int cur = 0;
-  for (uint32_t lvl = 0; lvl < pg->pcr_levels; ++lvl) {
-    hipLaunchKernelGGL(nos::pgo_pcr_apply_kernel, dim3(cblocks), dim3(128), 0, slot.stream, C, 1u << lvl,
-                       pg->c_alpha + size_t(lvl) * 36 * C, pg->c_gamma + size_t(lvl) * 36 * C, pg->c_b[cur], pg->c_b[1 - cur]);
-    cur = 1 - cur;
-  }
-  hipLaunchKernelGGL(nos::pgo_pcr_solve_kernel, dim3(cblocks), dim3(128), 0, slot.stream, C, pg->c_Dinv, pg->c_b[cur],
-                     pg->c_b[1 - cur]);
-  NOS_HIP_CHECK(hipGetLastError());
-  *xc = pg->c_b[1 - cur];
-  return NOS_OK;
+  return pgo_pcr_rhs(pg, xc);
 }
 
 }  // namespace
@@ -178,7 +204,7 @@ int nos_pgo_destroy(nos_pose_graph* pg) {
   if (!pg) return NOS_OK;
   void* bufs[] = {pg->d_pose, pg->d_ref, pg->d_qry, pg->d_edge, pg->d_adj_nbr, pg->d_sw_free, pg->d_fixed, pg->d_adj_off,
                   pg->d_adj, pg->d_hdiag, pg->d_minv, pg->d_hs, pg->d_grad, pg->d_x, pg->d_r, pg->d_z, pg->d_p,
-                  pg->d_ap, pg->d_partials, pg->d_scalars, pg->d_coarse};
+                  pg->d_ap, pg->d_partials, pg->d_scalars, pg->d_coarse, pg->d_tickets};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (pg->h_scalars) (void)hipHostFree(pg->h_scalars);
@@ -270,6 +296,8 @@ int nos_pgo_create(nos_ctx* ctx, size_t n_poses, const double* poses, size_t n_e
   dalloc(&pg->d_ap, pg->n_unknowns);
   dalloc(&pg->d_partials, size_t(2) * pg->partial_blocks);
   dalloc(&pg->d_scalars, 8);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&pg->d_tickets), 16);
+  if (e == hipSuccess) e = hipMemset(pg->d_tickets, 0, 16);
   if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&pg->h_scalars), sizeof(double) * 8, hipHostMallocDefault);
   if (e != hipSuccess) {
     nos_pgo_destroy(pg);
@@ -388,23 +416,29 @@ int nos_pgo_solve(nos_pose_graph* pg, double lambda, int max_iterations, double 
     const double stop = rel_tolerance * b_norm;
     while (it < max_iterations) {
       const int batch = std::min(kCheck, max_iterations - it);
+      // one PCG iteration = 6 launches (4 without the coarse level): product (+ p.Ap, alpha) · update + restriction ·
+      // PCR spans (2 at 1 M poses) · preconditioner (+ r.z, r.r, beta) · direction
+      const uint32_t pose_blocks = (pg->n_poses + 255) / 256;
+      const uint32_t mv_blocks = pose_blocks + (pg->n_free_switches > 0 ? (pg->n_edges + 255) / 256 : 0u);
+      const nos::PgoTail mv_tail{pg->d_partials, pg->d_tickets, pg->d_scalars};
+      const nos::PgoTail pc_tail{pg->d_partials, pg->d_tickets + 1, pg->d_scalars};
       for (int k = 0; k < batch; ++k) {
-        rc = pgo_matvec(pg, lambda, pg->d_p, pg->d_ap, nullptr);
-        if (rc != NOS_OK) return rc;
-        {
-          uint32_t blocks = (pg->n_poses + 255) / 256;
-          if (pg->n_free_switches > 0) blocks += (pg->n_edges + 255) / 256;
-          hipLaunchKernelGGL(nos::pgo_sum_partials_kernel, dim3(1), dim3(1024), 0, slot.stream, pg->d_partials, blocks, 1,
-                             pg->d_scalars);
+        hipLaunchKernelGGL(nos::pgo_matvec_cg_kernel, dim3(mv_blocks), dim3(256), 0, slot.stream, pg->view, pg->d_hdiag,
+                           pg->d_hs, lambda, pg->d_p, pg->d_ap, pose_blocks, mv_tail);
+        const double* xc = nullptr;
+        if (two_level) {
+          const uint32_t ur_blocks = (pg->n_agg + 3) / 4 + (active_edges + 255) / 256;
+          hipLaunchKernelGGL(nos::pgo_update_restrict_kernel, dim3(ur_blocks), dim3(256), 0, slot.stream, pg->view, agg,
+                             pg->n_agg, n, pg->d_scalars, pg->d_p, pg->d_ap, pg->d_x, pg->d_r, pg->c_b[0]);
+          rc = pgo_pcr_rhs(pg, &xc);
+          if (rc != NOS_OK) return rc;
+        } else {
+          hipLaunchKernelGGL(nos::pgo_cg_update_dev_kernel, dim3(vblocks), dim3(256), 0, slot.stream, n, pg->d_scalars, pg->d_p,
+                             pg->d_ap, pg->d_x, pg->d_r);
         }
-        hipLaunchKernelGGL(nos::pgo_cg_alpha_kernel, dim3(1), dim3(1), 0, slot.stream, pg->d_scalars);
-        hipLaunchKernelGGL(nos::pgo_cg_update_dev_kernel, dim3(vblocks), dim3(256), 0, slot.stream, n, pg->d_scalars, pg->d_p,
-                           pg->d_ap, pg->d_x, pg->d_r);
-        rc = apply_precond();
-        if (rc != NOS_OK) return rc;
-        hipLaunchKernelGGL(nos::pgo_sum_partials_kernel, dim3(1), dim3(1024), 0, slot.stream, pg->d_partials, pblocks, 2,
-                           pg->d_scalars);
-        hipLaunchKernelGGL(nos::pgo_cg_beta_kernel, dim3(1), dim3(1), 0, slot.stream, pg->d_scalars);
+        hipLaunchKernelGGL(nos::pgo_apply_precond_kernel, dim3(pblocks), dim3(256), 0, slot.stream, pg->d_minv, pg->d_hs,
+                           lambda, pg->n_poses, active_edges, pg->d_r, pg->d_r + N6, pg->d_z, pg->d_z + N6, pg->d_partials,
+                           pg->d_pose, pg->d_fixed, xc, agg, pc_tail);
         hipLaunchKernelGGL(nos::pgo_cg_direction_dev_kernel, dim3(vblocks), dim3(256), 0, slot.stream, n, pg->d_scalars,
                            pg->d_z, pg->d_p);
         NOS_HIP_CHECK(hipGetLastError());
@@ -499,6 +533,44 @@ int nos_pgo_get_vector(nos_pose_graph* pg, int which, double* out) {
   for (size_t i = 0; i < N; ++i)
     for (int k = 0; k < 6; ++k) out[size_t(k) * N + i] = rec[6 * i + k];
   for (size_t e = 0; e < pg->n_edges; ++e) out[6 * N + e] = rec[6 * N + e];
+  return NOS_OK;
+}
+
+// Timing aid: `repeats` sweeps back to back between one pair of events (bench.py; nothing else uses it).
+int nos_pgo_time_sweep(nos_pose_graph* pg, int which, double lambda, int repeats, double* ms_per_sweep) {
+  nosd::CtxGuard guard_(pg ? pg->ctx : nullptr);  // one solve / accumulate / create at a time per context
+  if (!pg || !ms_per_sweep || repeats < 1 || which < 0 || which > 1) return fail(NOS_ERR_INVALID_ARGUMENT, "bad argument");
+  DeviceSlot& slot = pg->ctx->slots[0];
+  NOS_HIP_CHECK(hipSetDevice(slot.device));
+  const size_t N6 = size_t(6) * pg->n_poses;
+  const uint32_t pose_blocks = (pg->n_poses + 255) / 256;
+  const uint32_t mv_blocks = pose_blocks + (pg->n_free_switches > 0 ? (pg->n_edges + 255) / 256 : 0u);
+  const nos::PgoTail mv_tail{pg->d_partials, pg->d_tickets, pg->d_scalars};
+  if (which == 0) {  // x = gradient (its switch rows included)
+    NOS_HIP_CHECK(hipMemcpyAsync(pg->d_p, pg->d_grad, pg->n_unknowns * sizeof(double), hipMemcpyDeviceToDevice, slot.stream));
+    (void)N6;
+  }
+  auto sweep = [&]() {
+    if (which == 0) {
+      hipLaunchKernelGGL(nos::pgo_matvec_cg_kernel, dim3(mv_blocks), dim3(256), 0, slot.stream, pg->view, pg->d_hdiag, pg->d_hs,
+                         lambda, pg->d_p, pg->d_ap, pose_blocks, mv_tail);
+    } else {
+      hipLaunchKernelGGL(nos::pgo_linearize_kernel, dim3(pose_blocks), dim3(256), 0, slot.stream, pg->view, pg->d_hdiag,
+                         pg->d_grad, pg->d_partials);
+      if (pg->n_edges > 0)
+        hipLaunchKernelGGL(nos::pgo_switch_linearize_kernel, dim3((pg->n_edges + 255) / 256), dim3(256), 0, slot.stream,
+                           pg->view, pg->d_grad + size_t(6) * pg->n_poses, pg->d_hs);
+    }
+  };
+  sweep();  // warm
+  NOS_HIP_CHECK(hipEventRecord(slot.ev0, slot.stream));
+  for (int k = 0; k < repeats; ++k) sweep();
+  NOS_HIP_CHECK(hipEventRecord(slot.ev1, slot.stream));
+  NOS_HIP_CHECK(hipGetLastError());
+  NOS_HIP_CHECK(hipEventSynchronize(slot.ev1));
+  float ms = 0.f;
+  NOS_HIP_CHECK(hipEventElapsedTime(&ms, slot.ev0, slot.ev1));
+  *ms_per_sweep = double(ms) / repeats;
   return NOS_OK;
 }
 

@@ -186,6 +186,60 @@ __global__ __launch_bounds__(256) void pgo_coarse_restrict_kernel(PgoView G, uin
   }
 }
 
+// The vector update of a PCG iteration and the restriction of the new residual in ONE pass (device-resident CG scalars):
+//     x += alpha p,  r -= alpha q            (alpha = scalars[5], written by the product's tail)
+//     rc_J = Σ_{i in J} B_iᵀ r_i
+// Same lane ↔ pose assignment, same order of additions as pgo_cg_update_dev_kernel followed by pgo_coarse_restrict_kernel
+// (one wave per aggregate): identical bits, one sweep over r instead of two and one launch instead of two.  Workgroups
+// [0, ceil(n_agg / 4)) take the pose rows; the ones behind them the switch rows [6 n_poses, n) element-wise.
+__global__ __launch_bounds__(256) void pgo_update_restrict_kernel(PgoView G, uint32_t agg, uint32_t n_agg, size_t n,
+                                                                  const double* __restrict__ scalars,
+                                                                  const double* __restrict__ p, const double* __restrict__ q,
+                                                                  double* __restrict__ x, double* __restrict__ r,
+                                                                  double* __restrict__ rc) {
+  const double alpha = scalars[5];
+  const uint32_t agg_blocks = (n_agg + 3u) / 4u;
+  if (blockIdx.x >= agg_blocks) {
+    const size_t i = size_t(6) * G.n_poses + size_t(blockIdx.x - agg_blocks) * 256 + threadIdx.x;
+    if (i < n) {
+      x[i] += alpha * p[i];
+      r[i] -= alpha * q[i];
+    }
+    return;
+  }
+  const uint32_t J = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t lane = threadIdx.x & 63u;
+  if (J >= n_agg) return;  // wave-uniform
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+  const uint32_t lo = J * agg, hi = (lo + agg < G.n_poses) ? lo + agg : G.n_poses;
+  for (uint32_t i = lo + lane; i < hi; i += 64u) {
+    double yi[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const size_t u = size_t(6) * i + k;
+      x[u] += alpha * p[u];
+      const double rn = r[u] - alpha * q[u];
+      r[u] = rn;
+      yi[k] = rn;
+    }
+    if (G.fixed[i]) continue;
+    double B[36];
+    coarse_basis(G, i, agg, B);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      double v = acc[c];
+#pragma unroll
+      for (int rr = 0; rr < 6; ++rr) v = fma(B[6 * rr + c], yi[rr], v);
+      acc[c] = v;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    const double tot = wave_sum(acc[c]);
+    if (lane == 0) rc[size_t(6) * J + c] = tot;
+  }
+}
+
 // One probing product gives column `dof` of the blocks A_c(J, I) with I the aggregate of colour `colour` among J−1, J, J+1.
 // L / D / U: [n_agg][36] row-major blocks A_c(J, J−1), A_c(J, J), A_c(J, J+1).
 __global__ __launch_bounds__(128) void pgo_coarse_scatter_kernel(uint32_t n_agg, int colour, int dof,
@@ -348,6 +402,65 @@ __global__ __launch_bounds__(128) void pgo_pcr_solve_kernel(uint32_t n_agg, cons
   m6_mulvec_add(m, bi, xi);
 #pragma unroll
   for (int k = 0; k < 6; ++k) x[size_t(6) * J + k] = xi[k];
+}
+
+// Several PCR levels of the right-hand side in ONE launch (pgo_pcr_apply_kernel needs one launch per level: 15 at 1 M
+// poses, each a few µs of work behind a kernel boundary).  Level l couples row J with rows J ± 2^l only, so after the levels
+// [0, l0) the rows fall into 2^l0 independent residue classes J ≡ c (mod 2^l0); a workgroup takes T consecutive rows of one
+// class (position m ↔ row c + m 2^l0), keeps the right-hand side in LDS (ping-pong) and runs the levels [l0, l1):
+//   * halo > 0: the T positions include `halo` = 2^(l1-l0) - 1 positions on either side whose values go wrong level by
+//     level (their own neighbours are outside the workgroup) and are dropped: T - 2 halo positions are written;
+//   * halo = 0: the whole class fits the workgroup (rows_per_class <= T): no position is dropped, and with Dinv != nullptr
+//     the decoupled blocks are solved in the same launch (pgo_pcr_solve_kernel's x_J = D_J^-1 b_J).
+// Every row's arithmetic is that of pgo_pcr_apply_kernel, level by level: same bits.
+template <int T>
+__global__ __launch_bounds__(T) void pgo_pcr_span_kernel(uint32_t n_agg, uint32_t l0, uint32_t l1, uint32_t halo,
+                                                         const double* __restrict__ alpha, const double* __restrict__ gamma,
+                                                         const double* __restrict__ Dinv, const double* __restrict__ bin,
+                                                         double* __restrict__ bout) {
+  __shared__ double lds[2][T][6];
+  const uint32_t cls = blockIdx.x & ((1u << l0) - 1u), chunk = blockIdx.x >> l0;
+  const int tid = int(threadIdx.x);
+  const long long m = (long long)chunk * (T - 2 * int(halo)) + tid - int(halo);  // position inside the class
+  const long long J = (long long)cls + m * (1ll << l0);
+  const bool exists = m >= 0 && J < (long long)n_agg;
+  double b[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) b[k] = exists ? bin[size_t(6) * size_t(J) + k] : 0.0;
+  int cur = 0;
+  for (uint32_t l = l0; l < l1; ++l) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) lds[cur][tid][k] = b[k];
+    __syncthreads();
+    const long long d = 1ll << l;
+    const int dm = 1 << (l - l0);
+    if (exists) {
+      double xn[6], mat[36];
+      if (J >= d) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) xn[k] = tid - dm >= 0 ? lds[cur][tid - dm][k] : 0.0;
+        m6_load(alpha + (size_t(l) * n_agg + size_t(J)) * 36, mat);
+        m6_mulvec_add(mat, xn, b);
+      }
+      if (J + d < (long long)n_agg) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) xn[k] = tid + dm < T ? lds[cur][tid + dm][k] : 0.0;
+        m6_load(gamma + (size_t(l) * n_agg + size_t(J)) * 36, mat);
+        m6_mulvec_add(mat, xn, b);
+      }
+    }
+    cur ^= 1;
+  }
+  if (!exists || tid < int(halo) || tid >= T - int(halo)) return;
+  if (Dinv != nullptr) {
+    double mat[36], xi[6] = {0, 0, 0, 0, 0, 0};
+    m6_load(Dinv + size_t(36) * size_t(J), mat);
+    m6_mulvec_add(mat, b, xi);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) b[k] = xi[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) bout[size_t(6) * size_t(J) + k] = b[k];
 }
 
 }  // namespace nos

@@ -264,17 +264,102 @@ __global__ __launch_bounds__(256) void pgo_switch_linearize_kernel(PgoView G, do
   h_s[e] = rr + kSwitchPrior * kSwitchPrior;
 }
 
+// ---- block partials → one sum, in ONE fixed order whatever kernel does it
+//
+// The order is that of a 1024-lane workgroup: lane t strides the rows t, t + 1024, … with four independent accumulators
+// (rows t + 4096 k, + 1024, + 2048, + 3072; the ≤ 3 left-over rows go into the first), combines them as (s0 + s1) + (s2 + s3),
+// and the 1024 lane values are folded by halving (lane t += lane t + o, o = 512 … 1).  NT threads (1024, or 256 when the
+// sum runs in the tail of a sweep kernel) play the 1024 lanes, so the stand-alone kernel and the in-launch tails give the
+// same bits.  `lds` holds 1024 doubles.  The result is returned to thread 0 only.
+template <int NT>
+__device__ __forceinline__ double pgo_sum_rows(const double* __restrict__ partials, uint32_t count, int width, int w,
+                                               double* __restrict__ lds) {
+  for (uint32_t t = threadIdx.x; t < 1024u; t += NT) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    uint32_t i = t;
+    for (; i + 3 * 1024 < count; i += 4 * 1024) {
+      s0 += partials[size_t(i) * width + w];
+      s1 += partials[size_t(i + 1024) * width + w];
+      s2 += partials[size_t(i + 2 * 1024) * width + w];
+      s3 += partials[size_t(i + 3 * 1024) * width + w];
+    }
+    for (; i < count; i += 1024) s0 += partials[size_t(i) * width + w];
+    lds[t] = (s0 + s1) + (s2 + s3);
+  }
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    for (int t = int(threadIdx.x); t < o; t += NT) lds[t] += lds[t + o];
+    __syncthreads();
+  }
+  const double total = lds[0];
+  __syncthreads();
+  return total;
+}
+
+// In-launch tail of a sweep whose workgroups each publish `width` partial sums: the workgroup that arrives last adds all
+// rows up (pgo_sum_rows) and hands the totals to `finish` on its thread 0 — no dependent one-workgroup kernel and no
+// one-lane scalar kernel behind the sweep.  Hand-off = cdna_hip_programming.md Guideline 16, recipe R1: the partials are
+// stored write-through (agent-scope relaxed atomic stores = `global_store … sc1`) by thread 0, drained (`s_waitcnt
+// vmcnt(0)`), then thread 0 takes a ticket (agent-scope atomic add); the workgroup whose ticket is the last one acquires
+// (agent scope, L1 invalidate), waits for the invalidate, passes the workgroup barrier and reads the rows with plain
+// loads.  The ticket word is reset by the finisher: launches of one stream are ordered, so the next sweep finds it at 0.
+struct PgoTail {
+  double* partials;      // [gridDim.x][width]
+  unsigned int* ticket;  // one word per tail, zero between launches
+  double* scalars;       // the device-resident CG scalars (layout at pgo_cg_alpha_kernel)
+};
+
+template <int WIDTH>
+__device__ __forceinline__ void pgo_publish_partials(const PgoTail& T, const double (&v)[WIDTH]) {
+  // thread 0 only
+#pragma unroll
+  for (int w = 0; w < WIDTH; ++w)
+    __hip_atomic_store(T.partials + size_t(WIDTH) * blockIdx.x + w, v[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// → true on every thread of the workgroup that drew the last ticket (after the acquire).  `flag` = one LDS word.
+__device__ __forceinline__ bool pgo_tail_is_last(const PgoTail& T, unsigned int* flag) {
+  if (threadIdx.x == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-through partials have left before the ticket is drawn
+    const unsigned int old = __hip_atomic_fetch_add(T.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool last = old == gridDim.x - 1u;
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // holds the barrier below until the invalidate has completed
+      __hip_atomic_store(T.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    *flag = last ? 1u : 0u;
+  }
+  __syncthreads();
+  return *flag != 0u;
+}
+
+// CG scalar updates (the bodies of pgo_cg_alpha_kernel / pgo_cg_beta_kernel, shared with the in-launch tails).
+__device__ __forceinline__ void pgo_cg_alpha(double* __restrict__ s) {
+  const double pap = s[0];
+  if (s[7] != 0.0 || !(pap > 0.0) || !(pap <= 1.79769313486231570e308)) {
+    s[5] = 0.0;
+    s[7] = 1.0;
+  } else {
+    s[5] = s[4] / pap;
+  }
+}
+__device__ __forceinline__ void pgo_cg_beta(double* __restrict__ s) {
+  const double rz_new = s[0];
+  s[3] = s[1];
+  const double rz = s[4];
+  s[6] = (s[7] != 0.0 || !(rz > 0.0)) ? 0.0 : rz_new / rz;
+  if (s[7] == 0.0) s[4] = rz_new;
+}
+
 // y = (H + lambda diag(H)) x for the pose rows, matrix free, plus block partials of x.y (the p.Ap of CG).
 // x / y: [n_poses][6] records; xs: per-constraint switch components (0 where the switch is not free).
-__global__ __launch_bounds__(256) void pgo_matvec_pose_kernel(PgoView G, const double* __restrict__ hdiag,
-                                                              double lambda, const double* __restrict__ x,
-                                                              const double* __restrict__ xs,
-                                                              double* __restrict__ y,
-                                                              double* __restrict__ dot_partials,
-                                                              uint32_t mask_agg = 0) {
+// → this thread's share of x.y
+__device__ __forceinline__ double pgo_matvec_pose_row(const PgoView& G, const double* __restrict__ hdiag, double lambda,
+                                                      const double* __restrict__ x, const double* __restrict__ xs,
+                                                      double* __restrict__ y, uint32_t mask_agg, uint32_t i) {
   // mask_agg != 0: the coupling of constraints whose ends lie more than one aggregate (of mask_agg consecutive poses)
   // apart is dropped, their diagonal part stays — the operator the coarse level is probed with (pgo_coarse_kernels.hpp)
-  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   const size_t N = G.n_poses;
   double xy = 0.0;
   if (i < G.n_poses) {
@@ -321,21 +406,13 @@ __global__ __launch_bounds__(256) void pgo_matvec_pose_kernel(PgoView G, const d
   }
   }
   }
-  __shared__ double lds[4];
-  const double ws = wave_sum(xy);
-  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = ws;
-  __syncthreads();
-  if (threadIdx.x == 0) dot_partials[blockIdx.x] = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+  return xy;
 }
 
-// Switch rows of the same product.
-// Also emits block partials of xs.ys (appended after the pose blocks' partials by the caller).
-__global__ __launch_bounds__(256) void pgo_matvec_switch_kernel(PgoView G, const double* __restrict__ h_s, double lambda,
-                                                                const double* __restrict__ x,
-                                                                const double* __restrict__ xs,
-                                                                double* __restrict__ ys,
-                                                                double* __restrict__ dot_partials) {
-  const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+// Switch row of the same product → this thread's share of xs.ys.
+__device__ __forceinline__ double pgo_matvec_switch_row(const PgoView& G, const double* __restrict__ h_s, double lambda,
+                                                        const double* __restrict__ x, const double* __restrict__ xs,
+                                                        double* __restrict__ ys, uint32_t e) {
   double xy = 0.0;
   if (e < G.n_edges) {
     double out;
@@ -361,11 +438,68 @@ __global__ __launch_bounds__(256) void pgo_matvec_switch_kernel(PgoView G, const
     ys[e] = out;
     xy = xs[e] * out;
   }
-  __shared__ double lds[4];
-  const double ws = wave_sum(xy);
-  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = ws;
+  return xy;
+}
+
+// one value per thread → the workgroup's sum on thread 0 (4 waves, fixed order)
+__device__ __forceinline__ double pgo_block_sum256(double v, double* __restrict__ lds4) {
+  const double ws = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) lds4[threadIdx.x >> 6] = ws;
   __syncthreads();
-  if (threadIdx.x == 0) dot_partials[blockIdx.x] = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+  return (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
+}
+
+// The pose rows alone, block partials of x.y to dot_partials (the coarse level's probing products; host-scalar PCG).
+__global__ __launch_bounds__(256) void pgo_matvec_pose_kernel(PgoView G, const double* __restrict__ hdiag,
+                                                              double lambda, const double* __restrict__ x,
+                                                              const double* __restrict__ xs,
+                                                              double* __restrict__ y,
+                                                              double* __restrict__ dot_partials,
+                                                              uint32_t mask_agg = 0) {
+  const double xy = pgo_matvec_pose_row(G, hdiag, lambda, x, xs, y, mask_agg, blockIdx.x * 256 + threadIdx.x);
+  __shared__ double lds[4];
+  const double bs = pgo_block_sum256(xy, lds);
+  if (threadIdx.x == 0) dot_partials[blockIdx.x] = bs;
+}
+
+// Switch rows alone; block partials of xs.ys (appended after the pose blocks' partials by the caller).
+__global__ __launch_bounds__(256) void pgo_matvec_switch_kernel(PgoView G, const double* __restrict__ h_s, double lambda,
+                                                                const double* __restrict__ x,
+                                                                const double* __restrict__ xs,
+                                                                double* __restrict__ ys,
+                                                                double* __restrict__ dot_partials) {
+  const double xy = pgo_matvec_switch_row(G, h_s, lambda, x, xs, ys, blockIdx.x * 256 + threadIdx.x);
+  __shared__ double lds[4];
+  const double bs = pgo_block_sum256(xy, lds);
+  if (threadIdx.x == 0) dot_partials[blockIdx.x] = bs;
+}
+
+// The product of one PCG iteration in ONE launch: workgroups [0, pose_blocks) take the pose rows, the following ones the
+// switch rows (only launched when a switch is free), and the workgroup that finishes last adds the partials of p.Ap up
+// and computes the step length (pgo_cg_alpha) — what used to be product [+ switch product] + sum + alpha kernels.
+__global__ __launch_bounds__(256) void pgo_matvec_cg_kernel(PgoView G, const double* __restrict__ hdiag,
+                                                            const double* __restrict__ h_s, double lambda,
+                                                            const double* __restrict__ x, double* __restrict__ y,
+                                                            uint32_t pose_blocks, PgoTail tail) {
+  const size_t N6 = size_t(6) * G.n_poses;
+  double xy;
+  if (blockIdx.x < pose_blocks)
+    xy = pgo_matvec_pose_row(G, hdiag, lambda, x, x + N6, y, 0u, blockIdx.x * 256 + threadIdx.x);
+  else
+    xy = pgo_matvec_switch_row(G, h_s, lambda, x, x + N6, y + N6, (blockIdx.x - pose_blocks) * 256 + threadIdx.x);
+  __shared__ double lds[1024];
+  __shared__ unsigned int last_flag;
+  const double bs = pgo_block_sum256(xy, lds);
+  if (threadIdx.x == 0) {
+    const double v[1] = {bs};
+    pgo_publish_partials<1>(tail, v);
+  }
+  if (!pgo_tail_is_last(tail, &last_flag)) return;
+  const double total = pgo_sum_rows<256>(tail.partials, gridDim.x, 1, 0, lds);
+  if (threadIdx.x == 0) {
+    tail.scalars[0] = total;
+    pgo_cg_alpha(tail.scalars);
+  }
 }
 
 // Block-Jacobi preconditioner: inverse of the damped 6x6 diagonal block (Cholesky), stored as 21 upper
@@ -454,7 +588,8 @@ __global__ __launch_bounds__(256) void pgo_apply_precond_kernel(const double* __
                                                                 double* __restrict__ partials,
                                                                 const double* __restrict__ pose_rec = nullptr,
                                                                 const uint8_t* __restrict__ fixed = nullptr,
-                                                                const double* __restrict__ xc = nullptr, uint32_t agg = 0) {
+                                                                const double* __restrict__ xc = nullptr, uint32_t agg = 0,
+                                                                PgoTail tail = PgoTail{nullptr, nullptr, nullptr}) {
   // xc != nullptr: two-level form, z_i = M_ii^-1 r_i + B_i xc[aggregate of i] (coarse correction, pgo_coarse_kernels.hpp)
   const uint32_t t = blockIdx.x * 256 + threadIdx.x;
   double rz = 0.0, rr = 0.0;
@@ -503,16 +638,31 @@ __global__ __launch_bounds__(256) void pgo_apply_precond_kernel(const double* __
     rz = rs[e] * v;
     rr = rs[e] * rs[e];
   }
-  __shared__ double lds[4][2];
+  __shared__ double lds[1024];
+  __shared__ unsigned int last_flag;
   const double a = wave_sum(rz), b = wave_sum(rr);
   if ((threadIdx.x & 63) == 0) {
-    lds[threadIdx.x >> 6][0] = a;
-    lds[threadIdx.x >> 6][1] = b;
+    lds[2 * (threadIdx.x >> 6)] = a;
+    lds[2 * (threadIdx.x >> 6) + 1] = b;
   }
   __syncthreads();
+  const double v[2] = {(lds[0] + lds[2]) + (lds[4] + lds[6]), (lds[1] + lds[3]) + (lds[5] + lds[7])};
+  if (tail.ticket == nullptr) {  // host-read scalars: a separate sum kernel follows
+    if (threadIdx.x == 0) {
+      partials[2 * blockIdx.x] = v[0];
+      partials[2 * blockIdx.x + 1] = v[1];
+    }
+    return;
+  }
+  // device-resident CG scalars: the last workgroup sums r.z and r.r and computes beta (pgo_cg_beta)
+  if (threadIdx.x == 0) pgo_publish_partials<2>(tail, v);
+  if (!pgo_tail_is_last(tail, &last_flag)) return;
+  const double rz_total = pgo_sum_rows<256>(tail.partials, gridDim.x, 2, 0, lds);
+  const double rr_total = pgo_sum_rows<256>(tail.partials, gridDim.x, 2, 1, lds);
   if (threadIdx.x == 0) {
-    partials[2 * blockIdx.x] = (lds[0][0] + lds[1][0]) + (lds[2][0] + lds[3][0]);
-    partials[2 * blockIdx.x + 1] = (lds[0][1] + lds[1][1]) + (lds[2][1] + lds[3][1]);
+    tail.scalars[0] = rz_total;
+    tail.scalars[1] = rr_total;
+    pgo_cg_beta(tail.scalars);
   }
 }
 
@@ -553,21 +703,11 @@ __global__ __launch_bounds__(256) void pgo_cg_direction_kernel(size_t n, double 
 // s[7] = 1 after a breakdown (p·Ap <= 0 or not finite: the iterate is kept from then on).
 __global__ void pgo_cg_alpha_kernel(double* __restrict__ s) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const double pap = s[0];
-  if (s[7] != 0.0 || !(pap > 0.0) || !(pap <= 1.79769313486231570e308)) {
-    s[5] = 0.0;
-    s[7] = 1.0;
-  } else {
-    s[5] = s[4] / pap;
-  }
+  pgo_cg_alpha(s);
 }
 __global__ void pgo_cg_beta_kernel(double* __restrict__ s) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const double rz_new = s[0];
-  s[3] = s[1];
-  const double rz = s[4];
-  s[6] = (s[7] != 0.0 || !(rz > 0.0)) ? 0.0 : rz_new / rz;
-  if (s[7] == 0.0) s[4] = rz_new;
+  pgo_cg_beta(s);
 }
 __global__ __launch_bounds__(256) void pgo_cg_update_dev_kernel(size_t n, const double* __restrict__ s,
                                                                 const double* __restrict__ p, const double* __restrict__ q,
@@ -590,23 +730,8 @@ __global__ __launch_bounds__(1024) void pgo_sum_partials_kernel(const double* __
                                                                 int width, double* __restrict__ out) {
   __shared__ double lds[1024];
   for (int w = 0; w < width; ++w) {
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    uint32_t i = threadIdx.x;
-    for (; i + 3 * 1024 < count; i += 4 * 1024) {
-      s0 += partials[size_t(i) * width + w];
-      s1 += partials[size_t(i + 1024) * width + w];
-      s2 += partials[size_t(i + 2 * 1024) * width + w];
-      s3 += partials[size_t(i + 3 * 1024) * width + w];
-    }
-    for (; i < count; i += 1024) s0 += partials[size_t(i) * width + w];
-    lds[threadIdx.x] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) {
-      if (int(threadIdx.x) < o) lds[threadIdx.x] += lds[threadIdx.x + o];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) out[w] = lds[0];
-    __syncthreads();
+    const double total = pgo_sum_rows<1024>(partials, count, width, w, lds);
+    if (threadIdx.x == 0) out[w] = total;
   }
 }
 

@@ -74,6 +74,14 @@ class PoseGraph:
         check(self._lib.nos_pgo_matvec(self._h, ctypes.c_double(lam), _dp(x), _dp(y)), "nos_pgo_matvec")
         return y
 
+    def time_sweep(self, which, lam=1e-3, repeats=20):
+        """ms per device-resident sweep (nos_pgo_time_sweep): which = "matvec" (the product of a PCG iteration) or
+        "linearize" (the linearisation kernels, without the host's scalar readbacks)."""
+        ms = ctypes.c_double()
+        check(self._lib.nos_pgo_time_sweep(self._h, {"matvec": 0, "linearize": 1}[which], ctypes.c_double(lam), int(repeats),
+                                           ctypes.byref(ms)), "nos_pgo_time_sweep")
+        return ms.value
+
     def optimize(self, max_iterations=40, gradient_tolerance=1e-6, parameter_tolerance=1e-6, pcg_iterations=500,
                  pcg_tolerance=1e-10):
         """The reference's LM loop shape (always step; lambda x2 / x0.6 on the cost, clamp [1e-6, 1e-2]) driven

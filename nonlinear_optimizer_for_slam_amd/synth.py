@@ -22,6 +22,7 @@ def host_lib():
         _host = ctypes.CDLL(_lib.LIB_HOST)
         _host.nos_synth_true_pose.restype = None
         _host.nos_host_sizeof_ndt_correspondence.restype = ctypes.c_size_t
+        _host.nos_synth_room_points.restype = ctypes.c_size_t
     return _host
 
 
@@ -88,3 +89,59 @@ def pose_graph(n_poses, extra_per_pose=3, seed=SEED):
     fixed[0] = 1
     return {"true": true, "init": init, "ref": ref[:m].copy(), "qry": qry[:m].copy(), "meas": meas[:m].copy(),
             "fixed": fixed}
+
+
+# ---- the reference's own NDT test scene (input of the captured runs under results/)
+
+def room_points():
+    """[954605, 3]: GenerateGlobalPoints of the reference's NDT test drivers (MDM/tests/simple_optimization_test.cc:170-204)."""
+    lib = host_lib()
+    n = lib.nos_synth_room_points(None, ctypes.c_size_t(0))
+    out = np.zeros((n, 3))
+    lib.nos_synth_room_points(out.ctypes.data_as(_lib.c_double_p), ctypes.c_size_t(n))
+    return out
+
+
+def _harness_voxel_keys(points, inv_res):
+    """ComputeVoxelKey of the harness (…test.cc:283-294): zig-zag of the floored coordinates, two Cantor pairings."""
+    k = np.floor(points * inv_res).astype(np.int64)
+    k = np.where(k >= 0, 2 * k, -2 * k - 1)
+    xy = (k[:, 0] + k[:, 1]) * (k[:, 0] + k[:, 1] + 1) // 2 + k[:, 1]
+    return ((xy + k[:, 2]) * (xy + k[:, 2] + 1) // 2 + k[:, 2]).astype(np.uint64)
+
+
+def room_scan(points, voxel_size=0.1, t_true=(-0.2, 0.123, 0.3), yaw_true=0.1):
+    """FilterPoints (first point of every voxel of edge voxel_size, in point order; …test.cc:206-234) followed by
+    WarpPoints(true_pose^-1) (:85-92): the scan of the reference's "simple" test by default (results/maha_amd64_simple.txt).
+    → (local points [n, 3], R_true [3, 3], t_true [3])."""
+    keys = _harness_voxel_keys(points, 1.0 / voxel_size)
+    _, first = np.unique(keys, return_index=True)
+    f = points[np.sort(first)]
+    c, s = np.cos(yaw_true), np.sin(yaw_true)
+    Rt = np.array([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]])
+    tt = np.asarray(t_true, dtype=np.float64)
+    return (Rt.T @ (f - tt).T).T, Rt, tt
+
+
+def reference_reprojection_scene():
+    """The reference's reprojection test scene (REM/tests/simple_optimization_test.cc:43-61,115-160): 30 x 21 planar grid at
+    z = 3, loop variables accumulated in floating point as there, exact projections through true_pose^-1.
+    → (planes [5, 630], (fx, fy, cx, cy), R_true, t_true)."""
+    pts = []
+    x = -1.5
+    while x <= 1.5:
+        y = -1.0
+        while y <= 1.0:
+            pts.append((x, y, 3.0))
+            y += 0.1
+        x += 0.1
+    pts = np.array(pts)
+    fx = fy = 525.0
+    cx, cy = 320.0, 240.0
+    c, s = np.cos(0.1), np.sin(0.1)
+    Rt = np.array([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]])
+    tt = np.array([-0.1, 0.123, -0.5])
+    q = (Rt.T @ (pts - tt).T).T
+    inv_z = 1.0 / q[:, 2]
+    planes = np.stack([pts[:, 0], pts[:, 1], pts[:, 2], fx * q[:, 0] * inv_z + cx, fy * q[:, 1] * inv_z + cy])
+    return planes, (fx, fy, cx, cy), Rt, tt

@@ -304,3 +304,20 @@ def avx_ndt6_accumulate(planes_f32, R, t, loss=None, threads=1):
     if rc != 0:
         raise RuntimeError("oracle_avx_ndt6_accumulate failed: %d" % rc)
     return out
+
+
+def pack_records_f32(records, stride, field_offsets):
+    """The AoS → SoA pack loop of the reference's SIMD classes (MDM/..._analytic_simd.cc:19-28) restated: records =
+    n x stride bytes, 15 doubles per record at field_offsets → [15, n] float32 planes.  Single-threaded, as there."""
+    rec = np.ascontiguousarray(records).view(np.uint8).reshape(-1)
+    n = rec.size // stride
+    planes = np.empty((15, n), dtype=np.float32)
+    fp = ctypes.POINTER(ctypes.c_float)
+    arr = (fp * 15)(*[planes[k].ctypes.data_as(fp) for k in range(15)])
+    offs = (ctypes.c_size_t * 15)(*[int(o) for o in field_offsets])
+    fn = avx().oracle_pack_records_f32
+    fn.restype = ctypes.c_int
+    rc = fn(ctypes.c_size_t(n), rec.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(stride), offs, arr)
+    if rc != 0:
+        raise RuntimeError("oracle_pack_records_f32 failed: %d" % rc)
+    return planes

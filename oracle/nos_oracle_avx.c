@@ -47,6 +47,7 @@ typedef struct avx_job {
   int kind;      /* 0: 6-DoF NDT, 1: 3-DoF NDT, 2: reprojection */
   oracle_loss loss;
   double out28[28];
+  int created; /* its thread exists (pthread_create succeeded) */
 } avx_job;
 
 static inline float hsum8(__m256 v) {
@@ -263,6 +264,7 @@ typedef struct avx_job_f64 {
   double R[9], t[3];
   oracle_loss loss;
   double out28[28];
+  int created;
 } avx_job_f64;
 
 static inline double hsum4(__m256d v) {
@@ -421,8 +423,14 @@ static int avx_run(int kind, size_t n, const float* const* planes, const double*
   if (threads == 1) {
     avx_thread(&jobs[0]);
   } else {
-    for (i = 0; i < threads; ++i) pthread_create(&tids[i], NULL, avx_thread, &jobs[i]);
-    for (i = 0; i < threads; ++i) pthread_join(tids[i], NULL);
+    /* a thread that cannot be created (process / thread limit of the box) has its batch run inline: the sums are complete
+     * either way, and no join is attempted on a thread id that was never filled in */
+    for (i = 0; i < threads; ++i) {
+      jobs[i].created = pthread_create(&tids[i], NULL, avx_thread, &jobs[i]) == 0;
+      if (!jobs[i].created) avx_thread(&jobs[i]);
+    }
+    for (i = 0; i < threads; ++i)
+      if (jobs[i].created) pthread_join(tids[i], NULL);
   }
   memset(out, 0, (size_t)n_out * sizeof(double));
   for (i = 0; i < threads; ++i)
@@ -484,13 +492,39 @@ int oracle_avx_ndt6_accumulate_f64(size_t n, const double* const planes[15], con
   if (threads == 1) {
     avx_thread_f64(&jobs[0]);
   } else {
-    for (i = 0; i < threads; ++i) pthread_create(&tids[i], NULL, avx_thread_f64, &jobs[i]);
-    for (i = 0; i < threads; ++i) pthread_join(tids[i], NULL);
+    for (i = 0; i < threads; ++i) {  /* as above: a batch whose thread cannot be created runs inline */
+      jobs[i].created = pthread_create(&tids[i], NULL, avx_thread_f64, &jobs[i]) == 0;
+      if (!jobs[i].created) avx_thread_f64(&jobs[i]);
+    }
+    for (i = 0; i < threads; ++i)
+      if (jobs[i].created) pthread_join(tids[i], NULL);
   }
   memset(out28, 0, 28 * sizeof(double));
   for (i = 0; i < threads; ++i)
     for (k = 0; k < 28; ++k) out28[k] += jobs[i].out28[k];
   free(jobs);
   free(tids);
+  return 0;
+}
+
+/* ---------------------------------------------------------------- AoS -> SoA pack (CPU baseline of the ingestion stage)
+ *
+ * Restates the loop every SIMD-class Solve() opens with (MDM/mahalanobis_distance_minimizer_analytic_simd.cc:19-28):
+ *   for each correspondence: points.Append(corr.point.cast<float>()); means.Append(corr.ndt.mean.cast<float>());
+ *                            sqrt_infos.Append(corr.ndt.sqrt_information.cast<float>());
+ * i.e. 15 doubles gathered out of every 304-byte record (MDM/types.h:11-26) into 15 planar float arrays, single-threaded,
+ * in index order.  field_offset[f] = byte offset of plane f's double inside a record.  Returns 0. */
+int oracle_pack_records_f32(size_t n, const unsigned char* records, size_t stride, const size_t field_offset[15],
+                            float* const planes[15]) {
+  size_t i;
+  int f;
+  for (i = 0; i < n; ++i) {
+    const unsigned char* rec = records + i * stride;
+    for (f = 0; f < 15; ++f) {
+      double v;
+      memcpy(&v, rec + field_offset[f], sizeof v);
+      planes[f][i] = (float)v;
+    }
+  }
   return 0;
 }

@@ -182,6 +182,34 @@ def match_point_cloud(means, sqrt_infos, valid, local_points, R, t, radius_sq=1.
     return planes, int((idx >= 0).sum()), idx
 
 
+def match_point_cloud_kdtree(means, valid, world_points, radius_sq=1.0, max_neighbors=2, workers=1):
+    """MatchPointCloud's search as the reference runs it (MDM/tests/simple_optimization_test.cc:296-342): a k-d tree over
+    the valid voxel means, per point a radius search on SQUARED L2 distance < radius with max_neighbors = 2, sorted.  FLANN
+    (flann::KDTreeSingleIndex, un-vendored, absent here) is stood in for by scipy.spatial.cKDTree — the same data
+    structure and query; used as the CPU timing baseline of the matcher stage and checked against the brute-force
+    restatement above.  → (index array [n, 2] of original voxel ids, -1 = none; tree build seconds; query seconds).
+
+    Ties at equal distance are broken by tree order here and by voxel id in match_point_cloud: callers that compare the
+    two use inputs without exact ties."""
+    import time
+    from scipy.spatial import cKDTree
+    means = np.asarray(means, dtype=np.float64).reshape(-1, 3)
+    ok = np.ones(means.shape[0], dtype=bool) if valid is None else np.asarray(valid, dtype=bool)
+    ids = np.nonzero(ok)[0]
+    t0 = time.perf_counter()
+    tree = cKDTree(means[ids])
+    t1 = time.perf_counter()
+    q = np.asarray(world_points, dtype=np.float64).reshape(-1, 3)
+    k = min(max(int(max_neighbors), 1), 2)
+    # `distance_upper_bound` is exclusive like FLANN's `dist < radius` test; distances are Euclidean, so sqrt(radius)
+    d, j = tree.query(q, k=2, distance_upper_bound=float(np.sqrt(radius_sq)), workers=workers)
+    t2 = time.perf_counter()
+    idx = np.where(np.isfinite(d), ids[np.minimum(j, ids.size - 1)], -1).astype(np.int64)
+    if k < 2:
+        idx[:, 1] = -1
+    return idx, t1 - t0, t2 - t1
+
+
 # ----------------------------------------------------------------------------------------------
 # Bit-level restatement (oracle/scene_oracle.c): the accumulation of UpdateNdtMap and Eigen's
 # SelfAdjointEigenSolver<Matrix3d>, which together decide the captured COST lines.
