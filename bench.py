@@ -539,11 +539,12 @@ def main():
         # are brought up, self-tested and timed for R trains of K steps, and both results are printed.
         # NOS_BENCH_COMM = rccl | mailbox | torch restricts the set.
         want = os.environ.get("NOS_BENCH_COMM", "both")
-        order = {"both": ["rccl-native", "mailbox_device", "mailbox"], "auto": ["rccl-native", "mailbox_device", "mailbox"],
-                 "rccl": ["rccl-native"], "mailbox": ["mailbox"], "mailbox_device": ["mailbox_device"],
-                 "torch": []}.get(want, ["rccl-native", "mailbox_device", "mailbox"])
+        every = ["rccl-native", "mailbox_device_one_launch", "mailbox_device", "mailbox"]
+        order = {"both": every, "auto": every, "rccl": ["rccl-native"], "mailbox": ["mailbox"], "mailbox_device": ["mailbox_device"],
+                 "mailbox_device_one_launch": ["mailbox_device_one_launch"], "torch": []}.get(want, every)
         if shared_gpu:
             order = [c for c in order if c != "rccl-native"]  # RCCL refuses two ranks on one device
+            ctx.set_option("lm_cluster_max_blocks", max(1, 256 // world))  # all ranks' one-launch grids resident together
 
         def bring_up(candidate):
             ok, micros, seen = 1.0, 0.0, 0
@@ -551,7 +552,7 @@ def main():
                 with _StdoutToStderr():
                     if candidate == "mailbox":
                         ctx.comm_init_shm_from_torch()
-                    elif candidate == "mailbox_device":
+                    elif candidate.startswith("mailbox_device"):
                         ctx.comm_init_shm_from_torch(device_memory=True)
                     else:
                         ctx.comm_init_from_torch()
@@ -580,17 +581,25 @@ def main():
             if up is None:
                 continue
             it = (lambda k: work.iterate_device(ds, k)) if args.loop == "device" else (lambda k: work.iterate_host(ds, k))
-            legs[candidate] = run_trains(it, bracket=(candidate.startswith("mailbox") and args.loop == "device"))
+            # the device-memory mailbox keeps the one-launch loop (its exchange is a stage of the in-launch all-reduce);
+            # "mailbox_device" times the same transport under the launch-per-iteration loop (lm_cluster = 0), round 3's form
+            keep = ctx.get_option("lm_cluster")
+            if candidate == "mailbox_device":
+                ctx.set_option("lm_cluster", 0)
+            try:
+                legs[candidate] = run_trains(it, bracket=(candidate.startswith("mailbox") and args.loop == "device"))
+            finally:
+                ctx.set_option("lm_cluster", keep)
             legs[candidate].update(up)
+            legs[candidate]["launches_per_train"] = getattr(work, "launches_of_last_solve", None)
             if candidate == "rccl-native":
                 legs[candidate]["ncclCommCount"] = up["ranks_seen"]
             ctx.comm_destroy()
+        mailboxes = [c for c in legs if c.startswith("mailbox")]
         if "rccl-native" in legs:
             comm_mode = "rccl-native"
-        elif "mailbox_device" in legs:
-            comm_mode = "mailbox_device"
-        elif "mailbox" in legs:
-            comm_mode = "mailbox"
+        elif mailboxes:  # RCCL did not come up: the fastest mailbox form measured, not the first in a list
+            comm_mode = min(mailboxes, key=lambda c: legs[c]["ms_per_step"]["median"])
         else:
             # last resort: torch.distributed all_reduce (gloo here) from a Python callback around nos_ndt6_accumulate
             comm_mode = "torch.distributed(gloo)"
@@ -613,7 +622,8 @@ def main():
             legs[comm_mode] = run_trains(iterate_torch, bracket=False)
         legs["main"] = legs[comm_mode]
         comm_details = {k: {"ms_per_step": v["ms_per_step"], "allreduce_call_us": v.get("allreduce_call_us"),
-                            "ranks_seen": v.get("ranks_seen"), "ncclCommCount": v.get("ncclCommCount")}
+                            "ranks_seen": v.get("ranks_seen"), "ncclCommCount": v.get("ncclCommCount"),
+                            "launches_per_train": v.get("launches_per_train")}
                         for k, v in legs.items() if k != "main"}
 
     main_leg = legs["main"]

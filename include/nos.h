@@ -236,7 +236,9 @@ int nos_ndt_match(nos_ndt_map* map, nos_scan* scan, const double R[9], const dou
  * (MDM/..._analytic_simd.cc:46-51).  The reference's vector holds matches only, in scan order, nearest first
  * (MDM/tests/simple_optimization_test.cc:320-340); here absent neighbours are zero records, so "drop the last k
  * entries" is: clear the last n_drop NON-EMPTY records in slot order (on the device, asynchronously on the context's
- * stream).  Flat NDT datasets on single-device contexts. */
+ * stream).  "Empty" is decided by the sqrt-information: a record whose nine S entries are all zero counts as an absent
+ * neighbour (what the matcher writes for one) — a real match whose S is identically zero would be taken for empty, but it
+ * contributes nothing to the sums either way.  Flat NDT datasets on single-device contexts. */
 int nos_dataset_drop_last_matches(nos_dataset* ds, size_t n_drop);
 
 /* ---- voxel-indexed NDT datasets (additive; SURVEY.md §8d "voxel-indexed layout") ------
@@ -282,6 +284,13 @@ typedef struct nos_map_stats nos_map_stats;
  * exactly where the reference's -O2 -march=native x86-64 build fuses them (options "map_fma_mask", "map_eigen_version").
  * The map then equals the one the reference's test drivers build bit for bit (tests/golden/ndt_reference_map.npz), and
  * map build -> nos_ndt_match -> nos_ndt6_solve / nos_ndt3_solve reproduce the captured COST / iter lines of the reference's results directory.
+ * QUALIFICATION: identical when no voxel with >= 5 points is rejected by the eigenvalue test.  The reference's UpdateNdtMap
+ * leaves the function (`return`, not `continue`: .../tests/simple_optimization_test.cc:263-266) at the first such voxel, so
+ * every voxel its unordered_map walk would have visited later stays invalid; that order-dependent quirk is deliberately NOT
+ * reproduced — voxels are treated independently here (the reference's own room scene has no such voxel).  The defaults of
+ * "map_fma_mask" (which multiply-adds are fused, element by element) and the N/4 tail drop the captured 6-DoF runs need are
+ * CALIBRATED to the captured x86-64 runs, not derived from today's sources: parity unpinned for other builds
+ * of the reference (its aarch64 captures are followed with map_fma_mask = 0, as a band).
  * Voxels are listed in first-seen order (stats and voxel ids).  Not combinable with NOS_MAP_PROPER_SQRT_INFORMATION. */
 #define NOS_MAP_REFERENCE_EXACT 2
 int nos_ndt_map_build(nos_ctx* ctx, size_t n_points, const double* points_xyz,
@@ -365,7 +374,8 @@ typedef struct nos_lm_report {
   int32_t iterations;   /* loop index at exit: the "iter:" of the reference's stderr line */
   int32_t ok;           /* 0 if the damped solve met a non-positive pivot */
   int32_t launches;     /* kernels enqueued (>= iterations executed; the surplus exits at once) */
-  int32_t reserved;
+  int32_t fallback;     /* 1: the one-launch form of the loop gave up (GPU shared with another process, or the LDS it needs
+                           refused) and the solve was re-run with one launch per iteration — same result, slower */
   double printed_cost;  /* previous_cost at exit: the "COST:" of that line */
   double last_cost;
   double final_lambda;
@@ -378,6 +388,13 @@ int nos_ndt3_solve(nos_dataset* ds, double R2[4], double t2[2], const nos_loss* 
 int nos_reproj_solve(nos_dataset* ds, double R[9], double t[3], const double intr[4],
                      const nos_loss* loss, double min_depth, const nos_lm_options* options,
                      nos_lm_report* report);
+
+/* Test hook: ONE step of the device-resident loop on given sums and a given loop state — the stand-alone step kernel
+ * (the same single-lane function every device loop form calls).  dof 6: sums[28], dof 3: sums[10].
+ * state[22] = R (9, row-major; planar: R[0..3] = the 2x2 rotation) | t (3) | q w x y z (4) | lambda | previous_cost | cost |
+ * iteration | done | ok; settings[4] = max_iterations | gradient_tolerance | parameter_tolerance | float_schedule.
+ * state is updated in place.  The host's own step for the same arguments: nos_host_lm_advance in libnos_host.so. */
+int nos_debug_lm_step(nos_ctx* ctx, int dof, const double* sums, const double settings[4], double state[22]);
 
 /* ---- pose-graph optimisation (BASELINE.json configs[4]) --------
  * The reference's PoseGraphOptimizerAnalytic::Solve is an empty loop

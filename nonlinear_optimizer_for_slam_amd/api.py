@@ -225,7 +225,7 @@ def _lm_call(fn, where, pre_args, post_args, R, t, max_iterations, gradient_tole
     rep = NosLmReport()
     check(fn(*pre_args, _dp(R), _dp(t), *post_args, ctypes.byref(opt), ctypes.byref(rep)), where)
     executed = int(np.count_nonzero(~np.isnan(hist[:max(int(max_iterations), 0)])))
-    return R, t, {"iterations": rep.iterations, "ok": bool(rep.ok), "launches": rep.launches,
+    return R, t, {"iterations": rep.iterations, "ok": bool(rep.ok), "launches": rep.launches, "fallback": bool(rep.fallback),
                   "printed_cost": rep.printed_cost, "last_cost": rep.last_cost, "final_lambda": rep.final_lambda,
                   "cost_history": hist[:executed].copy()}
 

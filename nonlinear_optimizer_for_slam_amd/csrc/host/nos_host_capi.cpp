@@ -286,6 +286,33 @@ int nos_host_lm3_run(nos_host_accumulate3_fn accumulate, void* user, int max_ite
   return lm.ok ? 1 : 0;
 }
 
+// One step of the HOST loop (nos_host::LmAdvance6 / LmAdvance3) on given sums and a given state: the twin of
+// nos_debug_lm_step (include/nos.h), same argument layout.
+int nos_host_lm_advance(int dof, const double* sums, const double settings[4], double state[22]) {
+  if (!sums || !settings || !state || (dof != 6 && dof != 3)) return 1;
+  nos_host::LmState st;
+  for (int k = 0; k < 9; ++k) st.R[k] = state[k];
+  for (int k = 0; k < 3; ++k) st.t[k] = state[9 + k];
+  st.q.w = state[12], st.q.x = state[13], st.q.y = state[14], st.q.z = state[15];
+  st.lambda = state[16], st.previous_cost = state[17], st.cost = state[18];
+  st.iteration = int(state[19]), st.done = int(state[20]), st.ok = int(state[21]);
+  nos_host::LmSettings s;
+  s.max_iterations = int(settings[0]);
+  s.gradient_tolerance = settings[1];
+  s.parameter_tolerance = settings[2];
+  s.float_schedule = int(settings[3]);
+  if (dof == 6)
+    nos_host::LmAdvance6(s, sums, &st);
+  else
+    nos_host::LmAdvance3(s, sums, &st);
+  for (int k = 0; k < 9; ++k) state[k] = st.R[k];
+  for (int k = 0; k < 3; ++k) state[9 + k] = st.t[k];
+  state[12] = st.q.w, state[13] = st.q.x, state[14] = st.q.y, state[15] = st.q.z;
+  state[16] = st.lambda, state[17] = st.previous_cost, state[18] = st.cost;
+  state[19] = st.iteration, state[20] = st.done, state[21] = st.ok;
+  return 0;
+}
+
 int nos_host_damped_step6(const double out28[28], double lambda, double step[6]) {
   return nos_host::DampedStep<6>(out28, lambda, step) ? 1 : 0;
 }

@@ -24,6 +24,7 @@ int fail(int status, const char* fmt, ...) {
 }
 
 const char* last_error_text() { return g_last_error.c_str(); }
+void clear_last_error() { g_last_error.clear(); }
 
 // Directory of the shared object that provides `symbol` in this process ("" if unknown).
 static std::string dir_of_symbol(const void* symbol, std::string* file_out = nullptr) {
@@ -173,12 +174,6 @@ int launch_by_variant(int variant, int blocks_per_cu, int num_cus, const nos::Ti
     return launch_variant<Problem, T, ITEMS_, BLOCK_, MINW_>(L, P, bpc * num_cus, num_cus, nt, partials, fin, stream, \
                                                              rows_out);                             \
   }
-#define NOS_CASE_PF(idx, ITEMS_, BLOCK_, MINW_, BPC_)                                               \
-  case idx: {                                                                                       \
-    const int bpc = blocks_per_cu > 0 ? blocks_per_cu : BPC_;                                       \
-    return launch_variant<Problem, T, ITEMS_, BLOCK_, MINW_, 1>(L, P, bpc * num_cus, num_cus, nt, partials, fin, \
-                                                                stream, rows_out);                  \
-  }
 #define NOS_CASE_PP(idx, ITEMS_, BLOCK_, MINW_, BPC_)                                               \
   case idx: {                                                                                       \
     const int bpc = blocks_per_cu > 0 ? blocks_per_cu : BPC_;                                       \
@@ -205,8 +200,6 @@ int launch_by_variant(int variant, int blocks_per_cu, int num_cus, const nos::Ti
 #ifdef NOS_ALL_VARIANTS
       NOS_CASE(2, 1, 256, 2, 2)
       NOS_CASE(4, 2, 512, 2, 1)
-      NOS_CASE_PF(5, 1, 512, 2, 1)
-      NOS_CASE_PF(6, 1, 256, 2, 2)
       NOS_CASE_PP(8, 2, 512, 2, 1)
 #endif
     }
@@ -214,7 +207,6 @@ int launch_by_variant(int variant, int blocks_per_cu, int num_cus, const nos::Ti
     if (variant == 0) variant = kReproj ? 11 : 1;
     switch (variant) {
       NOS_CASE(1, 2, 512, 2, 1)      // 8-byte loads of two items, two waves per SIMD
-      NOS_CASE_PF(8, 2, 512, 2, 1)   // round 2's default on the tiled layout: the next chunk prefetched through register copies
       NOS_CASE_PP(11, 2, 512, 2, 1)  // ping-pong
 #ifdef NOS_ALL_VARIANTS
       NOS_CASE(2, 1, 256, 4, 2)
@@ -222,19 +214,16 @@ int launch_by_variant(int variant, int blocks_per_cu, int num_cus, const nos::Ti
       NOS_CASE(4, 2, 256, 4, 2)
       NOS_CASE(5, 1, 1024, 4, 1)  // four waves per SIMD, 4-byte loads
       NOS_CASE(6, 2, 1024, 4, 1)  // four waves per SIMD, 8-byte loads
-      NOS_CASE_PF(7, 4, 256, 2, 1)
       NOS_CASE(9, 2, 256, 3, 3)      // three waves per SIMD from three small workgroups per CU
-      NOS_CASE_PF(10, 2, 256, 3, 3)
       NOS_CASE_PP(12, 4, 512, 2, 1)
       NOS_CASE(13, 4, 256, 2, 1)     // round 1's default on planar planes: 16-byte loads, one wave per SIMD
 #endif
     }
   }
 #undef NOS_CASE
-#undef NOS_CASE_PF
 #undef NOS_CASE_PP
   return fail(NOS_ERR_UNSUPPORTED, "launch geometry %d is not compiled into this build for this element type "
-              "(default build: fp64 0, 1, 3, 7; fp32 1, 8, 11; `make ALL_VARIANTS=1` builds all)", variant);
+              "(default build: fp64 0, 1, 3, 7; fp32 1, 11; `make ALL_VARIANTS=1` builds the rest)", variant);
 }
 
 // Correspondences a lane of the resident one-launch solve can hold (registers + LDS), by plane count and element type.
@@ -253,10 +242,10 @@ struct SingleBlockArgs {
   // cluster form (one chunk per workgroup, whole loop in one launch) when cluster_blocks > 0
   int cluster_blocks = 0;
   int items_per_lane = 1;  // correspondences every lane keeps resident (registers + LDS, nos::ResidentShape)
-  int protocol = 1;        // hand-off form of the resident solve (Settings::lm_cluster == 3 selects 0)
   int stream_chunks = 0;   // > 0: the streaming form (nothing resident; this many chunks of 512 x SI per iteration)
   bool nt = false;         // streaming form: non-temporal loads
   bool stage1_sc1 = false; // keep stage 1 of the tagged all-reduce on sc1 stores even where a group sits on one XCD (lm_cluster 5)
+  const nos::Mailbox* mail = nullptr;  // device-memory mailbox communicator: the cross-rank exchange runs inside the launch
   double* partials = nullptr;
   nos::ClusterCtl* ctl = nullptr;
   nos::LmDevice* lm;
@@ -282,11 +271,12 @@ int launch_single(const nos::TiledLayout& L, const typename Problem::Params& P, 
     if (L.n_padded % kChunk != 0 || (L.tile_stride != 0 && ((size_t(L.tile_mask) + 1) % kChunk) != 0))
       return fail(NOS_ERR_INVALID_ARGUMENT, "streaming solve: layout not a multiple of the %zu-item chunk", kChunk);
     if (size_t(a.stream_chunks) * kChunk != L.n_padded) return fail(NOS_ERR_INVALID_ARGUMENT, "streaming solve: chunk count does not match the layout");
-    const auto kernel = a.nt ? nos::solve_cluster_kernel<Problem, T, kBlock, 0, 0, 1, kSI, kSPF, true>
-                             : nos::solve_cluster_kernel<Problem, T, kBlock, 0, 0, 1, kSI, kSPF, false>;
+    const auto kernel = a.nt ? nos::solve_cluster_kernel<Problem, T, kBlock, 0, 0, kSI, kSPF, true>
+                             : nos::solve_cluster_kernel<Problem, T, kBlock, 0, 0, kSI, kSPF, false>;
     t_last_kernel = reinterpret_cast<const void*>(kernel);
     hipLaunchKernelGGL(kernel, dim3(a.cluster_blocks), dim3(kBlock), 0, stream, L, P, a.partials, a.lm, a.ctl, a.history,
-                       a.history_capacity, a.entry, a.seq_host, a.seq, uint32_t(a.stream_chunks) | (a.stage1_sc1 ? 0x80000000u : 0u));
+                       a.history_capacity, a.entry, a.seq_host, a.seq, uint32_t(a.stream_chunks) | (a.stage1_sc1 ? 0x80000000u : 0u),
+                       a.mail);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(NOS_ERR_HIP, "streaming solve launch failed: %s", hipGetErrorString(e));
     return NOS_OK;
@@ -296,9 +286,7 @@ int launch_single(const nos::TiledLayout& L, const typename Problem::Params& P, 
     if (a.items_per_lane < 1 || a.items_per_lane > Shape::RI + Shape::LI)
       return fail(NOS_ERR_INVALID_ARGUMENT, "resident solve: %d items per lane do not fit (%d + %d)", a.items_per_lane,
                   Shape::RI, Shape::LI);
-    // a.protocol: 1 = tagged two-stage all-reduce (default), 0 = arrival counters + every workgroup reads every row
-    const auto kernel = a.protocol == 0 ? nos::solve_cluster_kernel<Problem, T, kBlock, Shape::RI, Shape::LI, 0>
-                                        : nos::solve_cluster_kernel<Problem, T, kBlock, Shape::RI, Shape::LI, 1>;
+    const auto kernel = nos::solve_cluster_kernel<Problem, T, kBlock, Shape::RI, Shape::LI>;
     const size_t lds_items = a.items_per_lane > Shape::RI ? size_t(a.items_per_lane - Shape::RI) : 0;
     const size_t dyn_bytes = lds_items * size_t(nos::resident_fields<Problem::kFields, sizeof(T)>()) * kBlock * sizeof(T);
     // Dynamic LDS beyond the default limit has to be granted per kernel AND per device (the attribute belongs to the
@@ -307,12 +295,13 @@ int launch_single(const nos::TiledLayout& L, const typename Problem::Params& P, 
     if (dyn_bytes > size_t(48) * 1024) {
       const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(dyn_bytes));
-      if (ea != hipSuccess) return fail(NOS_ERR_HIP, "resident solve: %zu bytes of LDS refused: %s", dyn_bytes, hipGetErrorString(ea));
+      // NOS_ERR_UNSUPPORTED: the one status for which lm_solve falls back to the launch-per-iteration loop
+      if (ea != hipSuccess) return fail(NOS_ERR_UNSUPPORTED, "resident solve: %zu bytes of LDS refused: %s", dyn_bytes, hipGetErrorString(ea));
     }
     t_last_kernel = reinterpret_cast<const void*>(kernel);
     hipLaunchKernelGGL(kernel, dim3(a.cluster_blocks), dim3(kBlock), dyn_bytes, stream, L, P, a.partials, a.lm, a.ctl,
                        a.history, a.history_capacity, a.entry, a.seq_host, a.seq,
-                       uint32_t(a.items_per_lane) | (a.stage1_sc1 ? 0x80000000u : 0u));
+                       uint32_t(a.items_per_lane) | (a.stage1_sc1 ? 0x80000000u : 0u), a.mail);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(NOS_ERR_HIP, "cluster solve launch failed: %s", hipGetErrorString(e));
     return NOS_OK;
@@ -762,7 +751,7 @@ int lm_solve(nos_dataset* ds, const Request& rq, const nos_lm_options* opt, doub
       report->iterations = st.iteration;
       report->ok = st.ok;
       report->launches = 1;
-      report->reserved = 0;
+      report->fallback = 0;
       report->printed_cost = st.previous_cost;
       report->last_cost = st.cost;
       report->final_lambda = st.lambda;
@@ -774,7 +763,15 @@ int lm_solve(nos_dataset* ds, const Request& rq, const nos_lm_options* opt, doub
   // launch gives up and the code below runs the loop with one launch per iteration instead.
   // One 512-thread workgroup per CU at most (all of them must be resident at once); every lane keeps items_per_lane
   // correspondences in registers + LDS.  lm_cluster: 0 off, 1 on, 2 = only the one-item-per-lane form of round 1.
-  const size_t max_blocks = std::min<size_t>(nos::kClusterMaxBlocks, size_t(slot.num_cus));
+  // lm_cluster_max_blocks: rehearsals of several ranks on ONE GPU give every rank its share of the CUs (all workgroups of
+  // all ranks have to be resident together)
+  const size_t max_blocks = std::min<size_t>(std::min<size_t>(nos::kClusterMaxBlocks, size_t(slot.num_cus)),
+                                             size_t(std::max(1, ctx->settings.lm_cluster_max_blocks)));
+  // A device-memory mailbox communicator keeps the one-launch loop: its exchange is a third stage inside the launch
+  // (solve_cluster_kernel).  RCCL and the host-memory mailbox run one launch per iteration, as before.
+  const bool mailbox_in_launch = ctx->shm_dev != nullptr && ctx->d_peers != nullptr && ctx->d_mail != nullptr &&
+                                 ds->kind != kKindNdtIndexed;
+  int fell_back = 0;
   const size_t cluster_blocks = std::min<size_t>(max_blocks, (sh.layout.n + 511) / 512);
   const size_t items_per_lane = cluster_blocks > 0 ? (sh.layout.n + cluster_blocks * 512 - 1) / (cluster_blocks * 512) : 0;
   const size_t resident_capacity = ctx->settings.lm_cluster == 2 ? 1 : resident_items_per_lane(ds->n_fields, ds->dtype);
@@ -788,7 +785,7 @@ int lm_solve(nos_dataset* ds, const Request& rq, const nos_lm_options* opt, doub
   if (slot.cluster_gave_up &&
       std::chrono::steady_clock::now() - slot.cluster_gave_up_at > std::chrono::milliseconds(ctx->settings.lm_cluster_retry_ms))
     slot.cluster_gave_up = false;  // try the one-launch form again
-  if (ds->kind != kKindNdtIndexed && !with_comm && ctx->shm_dev == nullptr && opt->max_iterations > 0 &&
+  if (ds->kind != kKindNdtIndexed && !with_comm && (ctx->shm_dev == nullptr || mailbox_in_launch) && opt->max_iterations > 0 &&
       cluster_blocks >= 1 && (resident_fits || stream_form) && !slot.cluster_gave_up &&
       ctx->settings.lm_cluster != 0 && (opt->cost_history == nullptr || opt->max_iterations <= kHistCapacity)) {
     SingleBlockArgs cl{};
@@ -799,8 +796,8 @@ int lm_solve(nos_dataset* ds, const Request& rq, const nos_lm_options* opt, doub
       cl.stream_chunks = int(sh.layout.n_padded / stream_chunk);
       cl.nt = use_nontemporal(ds, sh);
     }
-    cl.protocol = ctx->settings.lm_cluster == 3 ? 0 : 1;
     cl.stage1_sc1 = ctx->settings.lm_cluster == 5;
+    cl.mail = mailbox_in_launch ? ctx->d_mail : nullptr;
     cl.partials = slot.partials;
     cl.ctl = slot.d_cluster;
     cl.lm = slot.d_lm;
@@ -817,8 +814,11 @@ int lm_solve(nos_dataset* ds, const Request& rq, const nos_lm_options* opt, doub
       NOS_HIP_CHECK(hipStreamSynchronize(slot.stream));
     }
     int rows = 0;
-    // a launch that cannot be made (e.g. the LDS grant refused) is treated like one that gave up: the loop below runs instead
-    const bool launched_ok = launch_assemble_raw(ds, sh, rq, slot.partials, nos::FusedFinal{}, slot.stream, &rows, &cl) == NOS_OK;
+    // A launch the device cannot take (the LDS grant refused: NOS_ERR_UNSUPPORTED) is replaced by the loop below; any other
+    // failure — a layout / argument error, a sticky HIP error — is the caller's to see, not a reason to run slower.
+    const int rc_launch = launch_assemble_raw(ds, sh, rq, slot.partials, nos::FusedFinal{}, slot.stream, &rows, &cl);
+    if (rc_launch != NOS_OK && rc_launch != NOS_ERR_UNSUPPORTED) return rc_launch;
+    const bool launched_ok = rc_launch == NOS_OK;
     // spin on the sequence word; a launch that gave up never writes it
     volatile unsigned long long* seqw = reinterpret_cast<volatile unsigned long long*>(slot.h_out + kSeqSlot);
     bool finished = false;
@@ -863,19 +863,30 @@ int lm_solve(nos_dataset* ds, const Request& rq, const nos_lm_options* opt, doub
         report->iterations = st.iteration;
         report->ok = st.ok;
         report->launches = 1;
-        report->reserved = 0;
+        report->fallback = 0;
         report->printed_cost = st.previous_cost;
         report->last_cost = st.cost;
         report->final_lambda = st.lambda;
       }
       return NOS_OK;
     }
-    // gave up: put the shared words back in order and fall through to the launch-per-iteration loop from the start.
-    // A real give-up (not the test hook) means the GPU is shared: remember it for a while, so the next solves on this
-    // device do not each pay the bounded wait before falling back ("lm_cluster_retry_ms").
-    if (ctx->settings.debug_cluster_abort == 0) {
+    // gave up: put the shared words back in order and fall through to the launch-per-iteration loop from the start
+    // (reported as nos_lm_report::fallback).  A launch that ran and timed out means the GPU is shared: remember it for a
+    // while, so the next solves on this device do not each pay the bounded wait before falling back ("lm_cluster_retry_ms";
+    // debug_cluster_abort = 2 is the test hook that leaves this latch active).  A launch the device refused sets no latch,
+    // and the text of its refusal is dropped: the call goes on to succeed.
+    fell_back = 1;
+    if (launched_ok && ctx->settings.debug_cluster_abort != 1) {
       slot.cluster_gave_up = true;
       slot.cluster_gave_up_at = std::chrono::steady_clock::now();
+    }
+    if (!launched_ok) clear_last_error();
+    if (mailbox_in_launch) {
+      // every rank gives up together (a rank that cannot go on tells its peers); the exchange rounds the abandoned launch
+      // may have used are skipped on every rank, so that no later round finds their granules
+      hipLaunchKernelGGL(nos::mailbox_skip_rounds_kernel, dim3(1), dim3(1), 0, slot.stream, ctx->d_round,
+                         (unsigned long long)opt->max_iterations + 1ull);
+      NOS_HIP_CHECK(hipGetLastError());
     }
     NOS_HIP_CHECK(hipMemsetAsync(slot.d_cluster, 0, sizeof(nos::ClusterCtl), slot.stream));
     hipLaunchKernelGGL(nos::lm_init_kernel, dim3(1), dim3(1), 0, slot.stream, slot.d_lm, init);
@@ -962,7 +973,7 @@ int lm_solve(nos_dataset* ds, const Request& rq, const nos_lm_options* opt, doub
     report->iterations = st.iteration;
     report->ok = st.ok;
     report->launches = launched;
-    report->reserved = 0;
+    report->fallback = fell_back;
     report->printed_cost = st.previous_cost;
     report->last_cost = st.cost;
     report->final_lambda = st.lambda;
@@ -1438,6 +1449,7 @@ int nos_ctx_create(const int* device_ids, int n_devices, nos_ctx** out_ctx) {
     st.lm_window = env_int("NOS_LM_WINDOW", st.lm_window);
     st.lm_single = env_int("NOS_LM_SINGLE", st.lm_single);
     st.lm_cluster = env_int("NOS_LM_CLUSTER", st.lm_cluster);
+    st.lm_cluster_max_blocks = env_int("NOS_LM_CLUSTER_MAX_BLOCKS", st.lm_cluster_max_blocks);
     st.pool = env_int("NOS_POOL", st.pool);
     st.tile_log2 = env_int("NOS_TILE_LOG2", int(kDefaultTileLog2));
     const char* ingest = getenv("NOS_INGEST");
@@ -1448,6 +1460,8 @@ int nos_ctx_create(const int* device_ids, int n_devices, nos_ctx** out_ctx) {
     st.pgo_host_scalars = env_int("NOS_PGO_HOST_SCALARS", st.pgo_host_scalars);
     st.pgo_precond = env_int("NOS_PGO_PRECOND", st.pgo_precond);
     st.pgo_agg = env_int("NOS_PGO_AGG", st.pgo_agg);
+    st.pgo_block = env_int("NOS_PGO_BLOCK", st.pgo_block);
+    st.pgo_coarse_probe = env_int("NOS_PGO_COARSE_PROBE", st.pgo_coarse_probe);
     drop_out_of_range_settings(st);  // the same ranges nos_ctx_set_option enforces
   }
   for (int i = 0; i < n_devices; ++i) {
@@ -1614,9 +1628,12 @@ const OptionEntry kOptions[] = {
     {"pgo_host_scalars", &nosd::Settings::pgo_host_scalars, 0, 1},
     {"pgo_precond", &nosd::Settings::pgo_precond, 0, 1},
     {"pgo_agg", &nosd::Settings::pgo_agg, 2, 1 << 20},
+    {"pgo_block", &nosd::Settings::pgo_block, 0, 1},
+    {"pgo_coarse_probe", &nosd::Settings::pgo_coarse_probe, 0, 1},
     {"map_fma_mask", &nosd::Settings::map_fma_mask, 0, (1 << 26) - 1},
     {"map_eigen_version", &nosd::Settings::map_eigen_version, 33, 34},
-    {"debug_cluster_abort", &nosd::Settings::debug_cluster_abort, 0, 1},
+    {"debug_cluster_abort", &nosd::Settings::debug_cluster_abort, 0, 2},
+    {"lm_cluster_max_blocks", &nosd::Settings::lm_cluster_max_blocks, 1, 256},
 };
 bool option_in_range(const OptionEntry& o, int value);
 void drop_out_of_range_settings(nosd::Settings& st) {
@@ -1913,6 +1930,42 @@ int nos_reproj_time_kernel(nos_dataset* ds, const double R[9], const double t[3]
   return time_kernel(ds, rq, repeats, kernel_ms, total_ms);
 }
 
+int nos_debug_lm_step(nos_ctx* ctx, int dof, const double* sums, const double settings[4], double state[22]) {
+  nosd::CtxGuard guard_(ctx);  // one solve / accumulate / create at a time per context
+  if (!ctx || !sums || !settings || !state || (dof != 6 && dof != 3)) return fail(NOS_ERR_INVALID_ARGUMENT, "bad argument");
+  DeviceSlot& slot = ctx->slots[0];
+  NOS_HIP_CHECK(hipSetDevice(slot.device));
+  nos::LmDevice lmd{};
+  for (int k = 0; k < 9; ++k) lmd.st.R[k] = state[k];
+  for (int k = 0; k < 3; ++k) lmd.st.t[k] = state[9 + k];
+  lmd.st.q.w = state[12], lmd.st.q.x = state[13], lmd.st.q.y = state[14], lmd.st.q.z = state[15];
+  lmd.st.lambda = state[16], lmd.st.previous_cost = state[17], lmd.st.cost = state[18];
+  lmd.st.iteration = int(state[19]), lmd.st.done = int(state[20]), lmd.st.ok = int(state[21]);
+  lmd.settings.max_iterations = int(settings[0]);
+  lmd.settings.gradient_tolerance = settings[1];
+  lmd.settings.parameter_tolerance = settings[2];
+  lmd.settings.float_schedule = int(settings[3]);
+  const int n_out = dof == 6 ? 28 : 10;
+  NOS_HIP_CHECK(hipMemcpyAsync(slot.d_lm, &lmd, sizeof lmd, hipMemcpyHostToDevice, slot.stream));
+  NOS_HIP_CHECK(hipMemcpyAsync(slot.d_out, sums, sizeof(double) * n_out, hipMemcpyHostToDevice, slot.stream));
+  NOS_HIP_CHECK(hipStreamSynchronize(slot.stream));  // lmd is a stack object
+  if (dof == 6)
+    hipLaunchKernelGGL((nos::lm_step_kernel<28>), dim3(1), dim3(64), 0, slot.stream, slot.d_out, slot.d_lm,
+                       static_cast<double*>(nullptr), static_cast<unsigned long long*>(nullptr), 0ull);
+  else
+    hipLaunchKernelGGL((nos::lm_step_kernel<10>), dim3(1), dim3(64), 0, slot.stream, slot.d_out, slot.d_lm,
+                       static_cast<double*>(nullptr), static_cast<unsigned long long*>(nullptr), 0ull);
+  NOS_HIP_CHECK(hipGetLastError());
+  NOS_HIP_CHECK(hipMemcpyAsync(&lmd, slot.d_lm, sizeof lmd, hipMemcpyDeviceToHost, slot.stream));
+  NOS_HIP_CHECK(hipStreamSynchronize(slot.stream));
+  for (int k = 0; k < 9; ++k) state[k] = lmd.st.R[k];
+  for (int k = 0; k < 3; ++k) state[9 + k] = lmd.st.t[k];
+  state[12] = lmd.st.q.w, state[13] = lmd.st.q.x, state[14] = lmd.st.q.y, state[15] = lmd.st.q.z;
+  state[16] = lmd.st.lambda, state[17] = lmd.st.previous_cost, state[18] = lmd.st.cost;
+  state[19] = lmd.st.iteration, state[20] = lmd.st.done, state[21] = lmd.st.ok;
+  return NOS_OK;
+}
+
 int nos_comm_get_unique_id(unsigned char id[NOS_COMM_ID_BYTES]) {
   if (!id) return fail(NOS_ERR_INVALID_ARGUMENT, "id is NULL");
   RcclApi* api = Rccl();
@@ -2082,8 +2135,9 @@ int comm_init_mailbox(nos_ctx* ctx, int n_ranks, int rank, const char* shm_name,
     auto* hdr = reinterpret_cast<std::atomic<unsigned long long>*>(static_cast<char*>(host) + slots_bytes);
     hipIpcMemHandle_t* handles = reinterpret_cast<hipIpcMemHandle_t*>(hdr + 193);
     double* own = nullptr;
-    e = hipExtMallocWithFlags(reinterpret_cast<void**>(&own), slots_bytes, hipDeviceMallocFinegrained);
-    if (e == hipSuccess) e = hipMemset(own, 0, slots_bytes);
+    // second half: the granule slots of the one-launch loop's in-launch exchange (solve_cluster_kernel, stage 3)
+    e = hipExtMallocWithFlags(reinterpret_cast<void**>(&own), 2 * slots_bytes, hipDeviceMallocFinegrained);
+    if (e == hipSuccess) e = hipMemset(own, 0, 2 * slots_bytes);
     hipIpcMemHandle_t mine{};
     if (e == hipSuccess) e = hipIpcGetMemHandle(&mine, own);
     if (e == hipSuccess) e = hipDeviceSynchronize();

@@ -35,6 +35,7 @@ namespace nosd {
 
 // thread-local text of the last failure + status pass-through (defined in nos_core.hip)
 int fail(int status, const char* fmt, ...);
+void clear_last_error();  // a failure that was handled (a fallback that went on to succeed) leaves no text behind
 
 #define NOS_HIP_CHECK(expr)                                                               \
   do {                                                                                    \
@@ -139,7 +140,7 @@ struct Settings {
   int lm_window = 3;         // NOS_LM_WINDOW       launches kept in flight by the device loop
   int lm_single = 1;         // NOS_LM_SINGLE       whole solve in one workgroup for tiny problems
   int lm_cluster_retry_ms = 5000;  // after a one-launch solve gave up (GPU shared): how long the context goes straight to the launch-per-iteration loop
-  int lm_cluster = 1;        // NOS_LM_CLUSTER      whole solve in one launch (resident on chip, or streamed per iteration beyond that); 5 = all-reduce stage 1 always through sc1 stores, 4 = resident form only, 3 = counter protocol, 2 = one item per lane, 0 = off
+  int lm_cluster = 1;        // NOS_LM_CLUSTER      whole solve in one launch (resident on chip, or streamed per iteration beyond that); 5 = all-reduce stage 1 always through sc1 stores, 4 = resident form only, 3 = (round 2's counter all-reduce: removed in round 4, behaves like 1), 2 = one item per lane, 0 = off
   int pool = 1;              // NOS_POOL            device-buffer pool
   int tile_log2 = -1;        // NOS_TILE_LOG2       -1 = by element type (fp64 planar, fp32 1024-item tiles), 0 = planar
   int ingest = 0;            // NOS_INGEST          0 auto, 1 pack (host gather), 2 unpack (device)
@@ -149,12 +150,16 @@ struct Settings {
   int pgo_host_scalars = 0;  // NOS_PGO_HOST_SCALARS
   int pgo_precond = 1;       // NOS_PGO_PRECOND     0 block-Jacobi only, 1 two-level (rigid-motion coarse space)
   int pgo_agg = 48;          // NOS_PGO_AGG         poses per aggregate of the coarse level
+  int pgo_coarse_probe = 0;  // NOS_PGO_COARSE_PROBE 1 = coarse operator probed with 18 masked products (round 2) instead of assembled
+  int pgo_block = 1;         // NOS_PGO_BLOCK       block-local product (entry lists built by nos_pgo_create); 0 = owner-computes sweeps
   // NOS_MAP_REFERENCE_EXACT builds (mapexact_kernels.hpp): which multiply-adds are fused and which Eigen release's
   // deflation test / shift guard is followed.  Defaults = what reproduces the reference's captured x86-64 runs;
   // map_fma_mask = 0 follows the aarch64 captures (tests/test_reference_ndt_runs.py).
   int map_fma_mask = kMapReferenceFmaMask;
   int map_eigen_version = 34;
-  int debug_cluster_abort = 0;  // test hook (no environment name): the next one-launch solve finds `abort` raised
+  int debug_cluster_abort = 0;  // test hook (no environment name): the next one-launch solve finds `abort` raised; 2 = and the
+                                // give-up is remembered like a real one (the lm_cluster_retry_ms latch)
+  int lm_cluster_max_blocks = 256;  // NOS_LM_CLUSTER_MAX_BLOCKS  workgroups of the one-launch loop (rehearsals: ranks sharing a GPU)
 };
 }  // namespace nosd
 

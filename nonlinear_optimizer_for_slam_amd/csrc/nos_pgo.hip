@@ -21,13 +21,24 @@ struct nos_pose_graph {
   double *d_hdiag = nullptr, *d_minv = nullptr;  // 21 planes each
   double* d_hs = nullptr;                         // switch curvature
   double *d_grad = nullptr, *d_x = nullptr, *d_r = nullptr, *d_z = nullptr, *d_p = nullptr, *d_ap = nullptr;
+  double* d_p2 = nullptr;  // second direction buffer: the block-local product writes p_new = z + beta p while it reads p
   double *d_partials = nullptr, *d_scalars = nullptr;
   unsigned int* d_tickets = nullptr;  // [2] arrival counters of the in-launch tails (product, preconditioner); zero between launches
   double* h_scalars = nullptr;  // pinned [4]
   uint32_t partial_blocks = 0;
   nos::PgoView view{};
+  // block-local product (pgo_matvec_block_kernel): per-block entry lists; block_poses = 0 → owner-computes kernels
+  double* d_bent = nullptr;        // [n_entries][10]
+  uint32_t* d_bent_off = nullptr;  // [n_blocks + 1]
+  uint32_t* d_bent_edge = nullptr; // [n_entries] constraint of every entry (switch refresh after a retract)
+  uint32_t* d_bhalo = nullptr;     // halo pose ids, block after block
+  uint32_t* d_bhalo_off = nullptr; // [n_blocks + 1]
+  uint32_t block_poses = 0, n_blocks = 0, n_entries = 0;
+  int product_grid = 0;            // workgroups of the block-local product (what is resident), decided at the first launch
+  nos::PgoBlockView bview{};
   // coarse level of the two-level preconditioner (pgo_coarse_kernels.hpp), allocated on first use
   uint32_t agg = 0, n_agg = 0, pcr_levels = 0;
+  size_t pcr_pitch = 0;  // elements between two planes of the PCR factors (see PcrLevelLayout)
   double* d_coarse = nullptr;  // one allocation: L/D/U x 2, Dinv, alpha/gamma per level, rhs x 2
   double *c_L[2] = {nullptr, nullptr}, *c_D[2] = {nullptr, nullptr}, *c_U[2] = {nullptr, nullptr};
   double *c_Dinv = nullptr, *c_alpha = nullptr, *c_gamma = nullptr, *c_b[2] = {nullptr, nullptr};
@@ -55,31 +66,68 @@ int pgo_dot(nos_pose_graph* pg, const double* a, const double* b, double* out) {
   return pgo_read_scalars(pg, 1, out);
 }
 
-// y = A x on the device; if x_dot_y is given, also x.y (from block partials emitted by the same kernels).
+int pgo_launch_product(nos_pose_graph* pg, double lambda, const double* x, double* y, const double* z = nullptr,
+                       double* x_new = nullptr);
+
+// y = A x on the device and x.y to the host (host-read CG scalars, option pgo_host_scalars): the same product kernel and the
+// same in-launch sum as the device-resident form, the total read back from the scalar block.
 int pgo_matvec(nos_pose_graph* pg, double lambda, const double* x, double* y, double* x_dot_y) {
+  const int rc = pgo_launch_product(pg, lambda, x, y);
+  if (rc != NOS_OK || x_dot_y == nullptr) return rc;
+  return pgo_read_scalars(pg, 1, x_dot_y);
+}
+
+// The product of a PCG iteration with its in-launch tail (p.Ap, alpha): block-local form when the graph has its entry lists.
+// z / x_new (block-local form only): the vector multiplied is x_new = z + beta x, formed in the same launch (see the kernel).
+int pgo_launch_product(nos_pose_graph* pg, double lambda, const double* x, double* y, const double* z, double* x_new) {
   DeviceSlot& slot = pg->ctx->slots[0];
-  const size_t N6 = size_t(pg->n_poses) * 6;
-  const uint32_t pose_blocks = (pg->n_poses + 255) / 256;
-  uint32_t blocks = pose_blocks;
-  hipLaunchKernelGGL(nos::pgo_matvec_pose_kernel, dim3(pose_blocks), dim3(256), 0, slot.stream, pg->view, pg->d_hdiag, lambda,
-                     x, x + N6, y, pg->d_partials, 0u);
-  if (pg->n_free_switches > 0) {  // without free switches the switch rows of x and y stay identically zero
-    const uint32_t sw_blocks = (pg->n_edges + 255) / 256;
-    hipLaunchKernelGGL(nos::pgo_matvec_switch_kernel, dim3(sw_blocks), dim3(256), 0, slot.stream, pg->view, pg->d_hs, lambda,
-                       x, x + N6, y + N6, pg->d_partials + pose_blocks);
-    blocks += sw_blocks;
+  const nos::PgoTail tail{pg->d_partials, pg->d_tickets, pg->d_scalars};
+  const int switch_rows = pg->n_free_switches > 0 ? 1 : 0;
+  if (pg->block_poses != 0) {
+    constexpr int kP = 128, kT = 256;
+    const size_t lds = ((size_t(kP) + pg->bview.halo_cap) * 14 + size_t(pg->bview.slot_cap) * 6) * sizeof(double);
+    auto* kernel = nos::pgo_matvec_block_kernel<kP, kT>;
+    if (lds > size_t(48) * 1024) {
+      const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+      if (ea != hipSuccess) return fail(NOS_ERR_HIP, "pose-graph product: %zu bytes of LDS refused: %s", lds, hipGetErrorString(ea));
+    }
+    if (pg->product_grid == 0) {  // persistent workgroups: as many as are resident together
+      int per_cu = 0;
+      const hipError_t eo = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kernel), kT, lds);
+      if (eo != hipSuccess || per_cu < 1) per_cu = 1;
+      pg->product_grid = int(std::min<size_t>(pg->n_blocks, size_t(per_cu) * size_t(slot.num_cus)));
+    }
+    hipLaunchKernelGGL(kernel, dim3(unsigned(pg->product_grid)), dim3(kT), lds, slot.stream, pg->view, pg->bview, pg->d_hdiag,
+                       pg->d_hs, lambda, x, y, switch_rows, tail, z, x_new);
+  } else {
+    const uint32_t pose_blocks = (pg->n_poses + 255) / 256;
+    const uint32_t mv_blocks = pose_blocks + (switch_rows ? (pg->n_edges + 255) / 256 : 0u);
+    hipLaunchKernelGGL(nos::pgo_matvec_cg_kernel, dim3(mv_blocks), dim3(256), 0, slot.stream, pg->view, pg->d_hdiag, pg->d_hs,
+                       lambda, x, y, pose_blocks, tail);
   }
   NOS_HIP_CHECK(hipGetLastError());
-  if (x_dot_y != nullptr) {
-    hipLaunchKernelGGL(nos::pgo_sum_partials_kernel, dim3(1), dim3(1024), 0, slot.stream, pg->d_partials, blocks, 1,
-                       pg->d_scalars);
-    NOS_HIP_CHECK(hipGetLastError());
-    return pgo_read_scalars(pg, 1, x_dot_y);
-  }
   return NOS_OK;
 }
 
 // ---- coarse level (pgo_coarse_kernels.hpp)
+
+// The PCR levels run in spans of up to kPcrSpanLevels levels per launch (pgo_pcr_span_kernel); a span whose residue classes
+// fit one workgroup takes all remaining levels.  → first level of the span that contains level l.
+constexpr uint32_t kPcrSpanLevels = 4, kPcrSpanThreads = 128;
+uint32_t pcr_span_start(uint32_t n_agg, uint32_t levels, uint32_t l) {
+  uint32_t s = 0;
+  for (;;) {
+    const uint32_t rows = uint32_t((uint64_t(n_agg) + (1ull << s) - 1) >> s);
+    if (rows <= kPcrSpanThreads) return s;  // the last span: levels [s, levels)
+    const uint32_t k = std::min(kPcrSpanLevels, levels - s);
+    if (l < s + k) return s;
+    s += k;
+  }
+}
+nos::PcrLevelLayout pcr_layout(uint32_t n_agg, uint32_t levels, uint32_t l) {
+  const uint32_t shift = pcr_span_start(n_agg, levels, l);
+  return nos::PcrLevelLayout{shift, uint32_t((uint64_t(n_agg) + (1ull << shift) - 1) >> shift)};
+}
 
 int pgo_coarse_alloc(nos_pose_graph* pg, uint32_t agg) {
   if (pg->d_coarse != nullptr && pg->agg == agg) return NOS_OK;
@@ -92,7 +140,13 @@ int pgo_coarse_alloc(nos_pose_graph* pg, uint32_t agg) {
   pg->pcr_levels = 0;
   while ((1u << pg->pcr_levels) < pg->n_agg) ++pg->pcr_levels;
   const size_t blk = size_t(36) * pg->n_agg, vec = size_t(6) * pg->n_agg;
-  const size_t total = 6 * blk + blk + 2 * size_t(std::max<uint32_t>(pg->pcr_levels, 1)) * blk + 2 * vec;
+  pg->pcr_pitch = pg->n_agg;
+  for (uint32_t l = 0; l < pg->pcr_levels; ++l) {
+    const nos::PcrLevelLayout lay = pcr_layout(pg->n_agg, pg->pcr_levels, l);
+    pg->pcr_pitch = std::max(pg->pcr_pitch, (size_t(1) << lay.shift) * lay.rows);
+  }
+  const size_t fac = size_t(36) * pg->pcr_pitch;  // one level's alpha (or gamma) planes
+  const size_t total = 6 * blk + blk + 2 * size_t(std::max<uint32_t>(pg->pcr_levels, 1)) * fac + 2 * vec;
   NOS_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&pg->d_coarse), total * sizeof(double)));
   double* p = pg->d_coarse;
   for (int k = 0; k < 2; ++k) {
@@ -106,17 +160,17 @@ int pgo_coarse_alloc(nos_pose_graph* pg, uint32_t agg) {
   pg->c_Dinv = p;
   p += blk;
   pg->c_alpha = p;
-  p += size_t(std::max<uint32_t>(pg->pcr_levels, 1)) * blk;
+  p += size_t(std::max<uint32_t>(pg->pcr_levels, 1)) * fac;
   pg->c_gamma = p;
-  p += size_t(std::max<uint32_t>(pg->pcr_levels, 1)) * blk;
+  p += size_t(std::max<uint32_t>(pg->pcr_levels, 1)) * fac;
   pg->c_b[0] = p;
   p += vec;
   pg->c_b[1] = p;
   return NOS_OK;
 }
 
-// Probe A_c = P^T H' P (18 masked products), then the PCR elimination.  Uses d_p / d_ap as scratch: call before the
-// CG vectors are initialised.
+// A_c = P^T H' P (assembled directly; option pgo_coarse_probe: probed with 18 masked products), then the PCR elimination.
+// The probing form uses d_p / d_ap as scratch: call before the CG vectors are initialised.
 int pgo_coarse_setup(nos_pose_graph* pg, double lambda, uint32_t agg) {
   int rc = pgo_coarse_alloc(pg, agg);
   if (rc != NOS_OK) return rc;
@@ -124,26 +178,39 @@ int pgo_coarse_setup(nos_pose_graph* pg, double lambda, uint32_t agg) {
   const uint32_t N = pg->n_poses, C = pg->n_agg;
   const uint32_t pose_blocks = (N + 255) / 256, cblocks = (C + 127) / 128;
   const size_t N6 = size_t(6) * N;
-  NOS_HIP_CHECK(hipMemsetAsync(pg->c_L[0], 0, size_t(3) * 36 * C * sizeof(double), slot.stream));  // L, D, U of buffer 0
-  NOS_HIP_CHECK(hipMemsetAsync(pg->d_p + N6, 0, size_t(pg->n_edges) * sizeof(double), slot.stream));  // switch part of the probe
-  for (int colour = 0; colour < 3; ++colour)
-    for (int dof = 0; dof < 6; ++dof) {
-      hipLaunchKernelGGL(nos::pgo_coarse_probe_kernel, dim3(pose_blocks), dim3(256), 0, slot.stream, pg->view, agg, colour, dof,
-                         pg->d_p);
-      hipLaunchKernelGGL(nos::pgo_matvec_pose_kernel, dim3(pose_blocks), dim3(256), 0, slot.stream, pg->view, pg->d_hdiag,
-                         lambda, pg->d_p, pg->d_p + N6, pg->d_ap, pg->d_partials, agg);
-      hipLaunchKernelGGL(nos::pgo_coarse_restrict_kernel, dim3((C + 3) / 4), dim3(256), 0, slot.stream, pg->view, agg, C,
-                         pg->d_ap, pg->c_b[0]);
-      hipLaunchKernelGGL(nos::pgo_coarse_scatter_kernel, dim3(cblocks), dim3(128), 0, slot.stream, C, colour, dof, pg->c_b[0],
-                         pg->c_L[0], pg->c_D[0], pg->c_U[0]);
-    }
+  if (pg->ctx->settings.pgo_coarse_probe == 0) {
+    // the three block diagonals of A_c = P^T H' P, assembled directly: one sweep over the constraints each
+    const dim3 grid((C + 3) / 4);
+    hipLaunchKernelGGL(nos::pgo_coarse_assemble_kernel<0>, grid, dim3(256), 0, slot.stream, pg->view, pg->d_hdiag, lambda, agg, C,
+                       pg->c_D[0]);
+    hipLaunchKernelGGL(nos::pgo_coarse_assemble_kernel<1>, grid, dim3(256), 0, slot.stream, pg->view, pg->d_hdiag, lambda, agg, C,
+                       pg->c_L[0]);
+    hipLaunchKernelGGL(nos::pgo_coarse_assemble_kernel<2>, grid, dim3(256), 0, slot.stream, pg->view, pg->d_hdiag, lambda, agg, C,
+                       pg->c_U[0]);
+  } else {
+    // round 2's way, kept for comparison (option pgo_coarse_probe): A_c probed with 18 masked matrix-free products
+    NOS_HIP_CHECK(hipMemsetAsync(pg->c_L[0], 0, size_t(3) * 36 * C * sizeof(double), slot.stream));  // L, D, U of buffer 0
+    NOS_HIP_CHECK(hipMemsetAsync(pg->d_p + N6, 0, size_t(pg->n_edges) * sizeof(double), slot.stream));  // switch part of the probe
+    for (int colour = 0; colour < 3; ++colour)
+      for (int dof = 0; dof < 6; ++dof) {
+        hipLaunchKernelGGL(nos::pgo_coarse_probe_kernel, dim3(pose_blocks), dim3(256), 0, slot.stream, pg->view, agg, colour, dof,
+                           pg->d_p);
+        hipLaunchKernelGGL(nos::pgo_matvec_pose_kernel, dim3(pose_blocks), dim3(256), 0, slot.stream, pg->view, pg->d_hdiag,
+                           lambda, pg->d_p, pg->d_p + N6, pg->d_ap, pg->d_partials, agg);
+        hipLaunchKernelGGL(nos::pgo_coarse_restrict_kernel, dim3((C + 3) / 4), dim3(256), 0, slot.stream, pg->view, agg, C,
+                           pg->d_ap, pg->c_b[0]);
+        hipLaunchKernelGGL(nos::pgo_coarse_scatter_kernel, dim3(cblocks), dim3(128), 0, slot.stream, C, colour, dof, pg->c_b[0],
+                           pg->c_L[0], pg->c_D[0], pg->c_U[0]);
+      }
+  }
   hipLaunchKernelGGL(nos::pgo_coarse_symmetrize_kernel, dim3(cblocks), dim3(128), 0, slot.stream, C, pg->c_L[0], pg->c_D[0],
                      pg->c_U[0]);
   int cur = 0;
   for (uint32_t lvl = 0; lvl < pg->pcr_levels; ++lvl) {
     hipLaunchKernelGGL(nos::pgo_pcr_setup_kernel, dim3(cblocks), dim3(128), 0, slot.stream, C, 1u << lvl, pg->c_L[cur],
                        pg->c_D[cur], pg->c_U[cur], pg->c_L[1 - cur], pg->c_D[1 - cur], pg->c_U[1 - cur],
-                       pg->c_alpha + size_t(lvl) * 36 * C, pg->c_gamma + size_t(lvl) * 36 * C);
+                       pg->c_alpha + size_t(lvl) * 36 * pg->pcr_pitch, pg->c_gamma + size_t(lvl) * 36 * pg->pcr_pitch,
+                       pcr_layout(C, pg->pcr_levels, lvl), pg->pcr_pitch);
     cur = 1 - cur;
   }
   hipLaunchKernelGGL(nos::pgo_pcr_finish_kernel, dim3(cblocks), dim3(128), 0, slot.stream, C, pg->c_D[cur], pg->c_Dinv);
@@ -152,32 +219,29 @@ int pgo_coarse_setup(nos_pose_graph* pg, double lambda, uint32_t agg) {
 }
 
 // Right-hand side in c_b[0] → xc = A_c^-1 rhs; returns the buffer holding xc.  The ⌈log2 n_agg⌉ PCR levels run in
-// spans of up to 7 levels per launch (pgo_pcr_span_kernel): at 1 M poses / 20 834 aggregates two launches — levels 0-6 with
-// halos, then levels 7-14 and the block solves inside one workgroup per residue class — instead of 16.
+// spans (pcr_span_start): at 1 M poses / 20 834 aggregates three launches — levels 0-3 and 4-7 with halos (213 and 224
+// workgroups of 128 rows), then levels 8-14 and the block solves inside one workgroup per residue class (256) — instead of 16.
 int pgo_pcr_rhs(nos_pose_graph* pg, const double** xc) {
   DeviceSlot& slot = pg->ctx->slots[0];
   const uint32_t C = pg->n_agg, L = pg->pcr_levels;
-  constexpr uint32_t kSpanLevels = 7, kT = 512;
+  constexpr uint32_t kT = kPcrSpanThreads;
   int cur = 0;
   uint32_t l = 0;
   for (;;) {
     const uint32_t rows = uint32_t((uint64_t(C) + (1ull << l) - 1) >> l);  // rows of the largest residue class
     const double* a = pg->c_alpha;
     const double* g = pg->c_gamma;
+    const nos::PcrLevelLayout lay{l, rows};
     if (rows <= kT) {  // the rest of the levels and the block solves, one workgroup per class
-      if (rows <= 256)
-        hipLaunchKernelGGL(nos::pgo_pcr_span_kernel<256>, dim3(1u << l), dim3(256), 0, slot.stream, C, l, L, 0u, a, g,
-                           pg->c_Dinv, pg->c_b[cur], pg->c_b[1 - cur]);
-      else
-        hipLaunchKernelGGL(nos::pgo_pcr_span_kernel<512>, dim3(1u << l), dim3(512), 0, slot.stream, C, l, L, 0u, a, g,
-                           pg->c_Dinv, pg->c_b[cur], pg->c_b[1 - cur]);
+      hipLaunchKernelGGL(nos::pgo_pcr_span_kernel<kT>, dim3(1u << l), dim3(kT), 0, slot.stream, C, l, L, 0u, a, g,
+                         pg->pcr_pitch, lay, pg->c_Dinv, pg->c_b[cur], pg->c_b[1 - cur]);
       cur = 1 - cur;
       break;
     }
-    const uint32_t k = std::min(kSpanLevels, L - l), halo = (1u << k) - 1u, per = kT - 2 * halo;
+    const uint32_t k = std::min(kPcrSpanLevels, L - l), halo = (1u << k) - 1u, per = kT - 2 * halo;
     const uint32_t chunks = (rows + per - 1) / per;
-    hipLaunchKernelGGL(nos::pgo_pcr_span_kernel<512>, dim3(chunks << l), dim3(512), 0, slot.stream, C, l, l + k, halo, a, g,
-                       static_cast<const double*>(nullptr), pg->c_b[cur], pg->c_b[1 - cur]);
+    hipLaunchKernelGGL(nos::pgo_pcr_span_kernel<kT>, dim3(chunks << l), dim3(kT), 0, slot.stream, C, l, l + k, halo, a, g,
+                       pg->pcr_pitch, lay, static_cast<const double*>(nullptr), pg->c_b[cur], pg->c_b[1 - cur]);
     cur = 1 - cur;
     l += k;
   }
@@ -204,7 +268,7 @@ int nos_pgo_destroy(nos_pose_graph* pg) {
   if (!pg) return NOS_OK;
   void* bufs[] = {pg->d_pose, pg->d_ref, pg->d_qry, pg->d_edge, pg->d_adj_nbr, pg->d_sw_free, pg->d_fixed, pg->d_adj_off,
                   pg->d_adj, pg->d_hdiag, pg->d_minv, pg->d_hs, pg->d_grad, pg->d_x, pg->d_r, pg->d_z, pg->d_p,
-                  pg->d_ap, pg->d_partials, pg->d_scalars, pg->d_coarse, pg->d_tickets};
+                  pg->d_ap, pg->d_p2, pg->d_partials, pg->d_scalars, pg->d_coarse, pg->d_tickets, pg->d_bent, pg->d_bent_off, pg->d_bent_edge, pg->d_bhalo, pg->d_bhalo_off};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (pg->h_scalars) (void)hipHostFree(pg->h_scalars);
@@ -230,8 +294,10 @@ int nos_pgo_create(nos_ctx* ctx, size_t n_poses, const double* poses, size_t n_e
   const uint32_t N = uint32_t(n_poses), M = uint32_t(n_edges);
   // host-side 64-byte records + adjacency (once per graph)
   std::vector<double> pose_rec(size_t(8) * N, 0.0), edge_rec(size_t(8) * std::max<uint32_t>(M, 1), 0.0);
-  for (uint32_t i = 0; i < N; ++i)
+  for (uint32_t i = 0; i < N; ++i) {
     for (int k = 0; k < 7; ++k) pose_rec[size_t(8) * i + k] = poses[size_t(7) * i + k];
+    pose_rec[size_t(8) * i + 7] = (fixed && fixed[i]) ? 1.0 : 0.0;  // element 7 = "fixed" flag (block-local product)
+  }
   std::vector<uint8_t> swf(std::max<uint32_t>(M, 1), 0), fx(N, 0);
   uint32_t n_free = 0;
   for (uint32_t e = 0; e < M; ++e) {
@@ -260,6 +326,104 @@ int nos_pgo_create(nos_ctx* ctx, size_t n_poses, const double* poses, size_t n_e
       adj[cursor[qry[e]]++] = 2 * e + 1;
     }
   }
+  // Block-local product: per block of kBlockPoses consecutive poses, the constraints that touch it, in constraint order,
+  // each with the adjacency slots (positions relative to the block's first adjacency entry) of its ends inside the block and
+  // with its two poses as indices LOCAL to the block: < kBlockPoses = own pose, else kBlockPoses + position in the block's
+  // halo list (the other blocks' poses its constraints refer to, ascending).
+  constexpr uint32_t kBlockPoses = 128, kSlotLimit = 2304, kHaloLimit = 512;  // LDS: (128 + 512) x 112 B + 2304 x 48 B = 182 KB
+                                                                               // is the refusal line; a trajectory graph needs ≈ 70 KB
+  const uint32_t n_blocks = (N + kBlockPoses - 1) / kBlockPoses;
+  std::vector<uint32_t> bent_off(size_t(n_blocks) + 1, 0), bent_edge, bhalo, bhalo_off(size_t(n_blocks) + 1, 0);
+  std::vector<double> bent;
+  uint32_t slot_cap = 0, halo_cap = 0;
+  bool blocks_ok = ctx->settings.pgo_block != 0 && M > 0;
+  if (blocks_ok) {
+    for (uint32_t b = 0; b < n_blocks; ++b) {
+      const uint32_t lo = b * kBlockPoses, hi = std::min(N, lo + kBlockPoses);
+      slot_cap = std::max(slot_cap, adj_off[hi] - adj_off[lo]);
+    }
+    blocks_ok = slot_cap <= kSlotLimit;
+  }
+  if (blocks_ok) {
+    // two passes over the blocks, both spread over a few host threads (blocks are independent): sizes, then contents
+    struct Ent {
+      uint32_t e, slot_r, slot_q;
+    };
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned n_threads = std::min<unsigned>(std::min(16u, hw), std::max(1u, n_blocks / 64u));
+    auto for_blocks = [&](auto&& body) {
+      std::vector<std::thread> pool;
+      for (unsigned w = 0; w < n_threads; ++w)
+        pool.emplace_back([&, w]() {
+          const uint32_t per = (n_blocks + n_threads - 1) / n_threads;
+          const uint32_t b0 = std::min(n_blocks, w * per), b1 = std::min(n_blocks, b0 + per);
+          std::vector<Ent> ents;
+          std::vector<uint32_t> halo;
+          for (uint32_t b = b0; b < b1; ++b) {
+            const uint32_t lo = b * kBlockPoses, hi = std::min(N, lo + kBlockPoses), a0 = adj_off[lo];
+            ents.clear();
+            halo.clear();
+            for (uint32_t a = a0; a < adj_off[hi]; ++a) {
+              const uint32_t e = adj[a] >> 1, role = adj[a] & 1u;
+              ents.push_back({e, role == 0 ? a - a0 : nos::kPgoNoSlot, role == 0 ? nos::kPgoNoSlot : a - a0});
+              const uint32_t other = adj_nbr[a];
+              if (other < lo || other >= hi) halo.push_back(other);
+            }
+            // constraint order; the two adjacency positions of a constraint with both ends in the block become one entry
+            std::sort(ents.begin(), ents.end(), [](const Ent& x, const Ent& y) { return x.e < y.e; });
+            size_t n_out = 0;
+            for (size_t k = 0; k < ents.size(); ++k) {
+              if (n_out > 0 && ents[n_out - 1].e == ents[k].e) {
+                if (ents[k].slot_r != nos::kPgoNoSlot) ents[n_out - 1].slot_r = ents[k].slot_r;
+                if (ents[k].slot_q != nos::kPgoNoSlot) ents[n_out - 1].slot_q = ents[k].slot_q;
+              } else {
+                ents[n_out++] = ents[k];
+              }
+            }
+            ents.resize(n_out);
+            std::sort(halo.begin(), halo.end());
+            halo.erase(std::unique(halo.begin(), halo.end()), halo.end());
+            body(b, lo, hi, ents, halo);
+          }
+        });
+      for (std::thread& th : pool) th.join();
+    };
+    std::atomic<bool> too_large{false};
+    for_blocks([&](uint32_t b, uint32_t, uint32_t, const std::vector<Ent>& ents, const std::vector<uint32_t>& halo) {
+      bent_off[b + 1] = uint32_t(ents.size());
+      bhalo_off[b + 1] = uint32_t(halo.size());
+      if (halo.size() > kHaloLimit) too_large.store(true);
+    });
+    blocks_ok = !too_large.load();
+    if (blocks_ok) {
+      for (uint32_t b = 0; b < n_blocks; ++b) {
+        halo_cap = std::max(halo_cap, bhalo_off[b + 1]);
+        bent_off[b + 1] += bent_off[b];
+        bhalo_off[b + 1] += bhalo_off[b];
+      }
+      bent.resize(size_t(10) * bent_off[n_blocks]);
+      bent_edge.resize(bent_off[n_blocks]);
+      bhalo.resize(bhalo_off[n_blocks]);
+      for_blocks([&](uint32_t b, uint32_t lo, uint32_t hi, const std::vector<Ent>& ents, const std::vector<uint32_t>& halo) {
+        auto local = [&](uint32_t pose) -> uint32_t {
+          if (pose >= lo && pose < hi) return pose - lo;
+          return kBlockPoses + uint32_t(std::lower_bound(halo.begin(), halo.end(), pose) - halo.begin());
+        };
+        size_t k = bent_off[b];
+        for (const Ent& en : ents) {
+          double* rec = bent.data() + size_t(10) * k;
+          for (int q = 0; q < 8; ++q) rec[q] = edge_rec[size_t(8) * en.e + q];
+          const unsigned long long w8 = (unsigned long long)en.e | ((unsigned long long)local(uint32_t(ref[en.e])) << 32) |
+                                        ((unsigned long long)local(uint32_t(qry[en.e])) << 48);
+          const unsigned long long w9 = (unsigned long long)en.slot_r | ((unsigned long long)en.slot_q << 16);
+          memcpy(&rec[8], &w8, sizeof w8);
+          memcpy(&rec[9], &w9, sizeof w9);
+          bent_edge[k++] = en.e;
+        }
+        std::copy(halo.begin(), halo.end(), bhalo.begin() + bhalo_off[b]);
+      });
+    }
+  }
   nos_pose_graph* pg = new (std::nothrow) nos_pose_graph();
   if (!pg) return fail(NOS_ERR_OUT_OF_MEMORY, "host allocation failed");
   pg->ctx = ctx;
@@ -276,6 +440,16 @@ int nos_pgo_create(nos_ctx* ctx, size_t n_poses, const double* poses, size_t n_e
   if (e == hipSuccess) e = upload(&pg->d_fixed, fx);
   if (e == hipSuccess) e = upload(&pg->d_adj_off, adj_off);
   if (e == hipSuccess) e = upload(&pg->d_adj, adj);
+  if (blocks_ok) {
+    if (e == hipSuccess) e = upload(&pg->d_bent, bent);
+    if (e == hipSuccess) e = upload(&pg->d_bent_off, bent_off);
+    if (e == hipSuccess) e = upload(&pg->d_bent_edge, bent_edge);
+    if (e == hipSuccess) e = upload(&pg->d_bhalo, bhalo);
+    if (e == hipSuccess) e = upload(&pg->d_bhalo_off, bhalo_off);
+    pg->block_poses = kBlockPoses;
+    pg->n_blocks = n_blocks;
+    pg->n_entries = uint32_t(bent_edge.size());
+  }
   {
     std::vector<int32_t> r(ref, ref + M), q(qry, qry + M);
     if (e == hipSuccess) e = upload(&pg->d_ref, r);
@@ -294,6 +468,7 @@ int nos_pgo_create(nos_ctx* ctx, size_t n_poses, const double* poses, size_t n_e
   dalloc(&pg->d_z, pg->n_unknowns);
   dalloc(&pg->d_p, pg->n_unknowns);
   dalloc(&pg->d_ap, pg->n_unknowns);
+  dalloc(&pg->d_p2, pg->n_unknowns);
   dalloc(&pg->d_partials, size_t(2) * pg->partial_blocks);
   dalloc(&pg->d_scalars, 8);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&pg->d_tickets), 16);
@@ -315,6 +490,13 @@ int nos_pgo_create(nos_ctx* ctx, size_t n_poses, const double* poses, size_t n_e
   G.fixed = pg->d_fixed;
   G.n_poses = N;
   G.n_edges = M;
+  pg->bview.entries = pg->d_bent;
+  pg->bview.entry_off = pg->d_bent_off;
+  pg->bview.halo = pg->d_bhalo;
+  pg->bview.halo_off = pg->d_bhalo_off;
+  pg->bview.n_blocks = pg->n_blocks;
+  pg->bview.halo_cap = (halo_cap + 7u) & ~7u;
+  pg->bview.slot_cap = std::max<uint32_t>(slot_cap, 256u);  // the tail's sum re-uses the slots: >= 1024 doubles
   *out_pg = pg;
   return NOS_OK;
 }
@@ -410,6 +592,9 @@ int nos_pgo_solve(nos_pose_graph* pg, double lambda, int max_iterations, double 
     // CG scalars stay on the device (pgo_cg_alpha / beta kernels); the host looks at |r| only every kCheck iterations,
     // so up to kCheck - 1 iterations more than strictly needed may run (they only improve the step).
     constexpr int kCheck = 8;
+    bool dir_flip = false;
+    if (pg->block_poses != 0)  // the first product forms p = z + 0 * p_old: p_old must be finite
+      NOS_HIP_CHECK(hipMemsetAsync(pg->d_p, 0, pg->n_unknowns * sizeof(double), slot.stream));
     const double init[8] = {0.0, 0.0, 0.0, rr, rz, 0.0, 0.0, 0.0};
     NOS_HIP_CHECK(hipMemcpyAsync(pg->d_scalars, init, sizeof init, hipMemcpyHostToDevice, slot.stream));
     NOS_HIP_CHECK(hipStreamSynchronize(slot.stream));  // `init` is a stack array
@@ -418,29 +603,38 @@ int nos_pgo_solve(nos_pose_graph* pg, double lambda, int max_iterations, double 
       const int batch = std::min(kCheck, max_iterations - it);
       // one PCG iteration = 6 launches (4 without the coarse level): product (+ p.Ap, alpha) · update + restriction ·
       // PCR spans (2 at 1 M poses) · preconditioner (+ r.z, r.r, beta) · direction
-      const uint32_t pose_blocks = (pg->n_poses + 255) / 256;
-      const uint32_t mv_blocks = pose_blocks + (pg->n_free_switches > 0 ? (pg->n_edges + 255) / 256 : 0u);
-      const nos::PgoTail mv_tail{pg->d_partials, pg->d_tickets, pg->d_scalars};
       const nos::PgoTail pc_tail{pg->d_partials, pg->d_tickets + 1, pg->d_scalars};
+      // one PCG iteration = 6 launches with the block-local product (direction update inside the product: p ping-pongs
+      // between two buffers), 7 with the owner-computes product, 4 / 5 without the coarse level
+      const bool fuse_direction = pg->block_poses != 0;
       for (int k = 0; k < batch; ++k) {
-        hipLaunchKernelGGL(nos::pgo_matvec_cg_kernel, dim3(mv_blocks), dim3(256), 0, slot.stream, pg->view, pg->d_hdiag,
-                           pg->d_hs, lambda, pg->d_p, pg->d_ap, pose_blocks, mv_tail);
+        double* p_cur = pg->d_p;
+        if (fuse_direction) {  // p_new = z + beta p_old (beta = 0 and p_old = 0 before the first product: p = z)
+          double* p_old = dir_flip ? pg->d_p2 : pg->d_p;
+          p_cur = dir_flip ? pg->d_p : pg->d_p2;
+          rc = pgo_launch_product(pg, lambda, p_old, pg->d_ap, pg->d_z, p_cur);
+          dir_flip = !dir_flip;
+        } else {
+          rc = pgo_launch_product(pg, lambda, pg->d_p, pg->d_ap);
+        }
+        if (rc != NOS_OK) return rc;
         const double* xc = nullptr;
         if (two_level) {
           const uint32_t ur_blocks = (pg->n_agg + 3) / 4 + (active_edges + 255) / 256;
           hipLaunchKernelGGL(nos::pgo_update_restrict_kernel, dim3(ur_blocks), dim3(256), 0, slot.stream, pg->view, agg,
-                             pg->n_agg, n, pg->d_scalars, pg->d_p, pg->d_ap, pg->d_x, pg->d_r, pg->c_b[0]);
+                             pg->n_agg, n, pg->d_scalars, p_cur, pg->d_ap, pg->d_x, pg->d_r, pg->c_b[0]);
           rc = pgo_pcr_rhs(pg, &xc);
           if (rc != NOS_OK) return rc;
         } else {
-          hipLaunchKernelGGL(nos::pgo_cg_update_dev_kernel, dim3(vblocks), dim3(256), 0, slot.stream, n, pg->d_scalars, pg->d_p,
+          hipLaunchKernelGGL(nos::pgo_cg_update_dev_kernel, dim3(vblocks), dim3(256), 0, slot.stream, n, pg->d_scalars, p_cur,
                              pg->d_ap, pg->d_x, pg->d_r);
         }
         hipLaunchKernelGGL(nos::pgo_apply_precond_kernel, dim3(pblocks), dim3(256), 0, slot.stream, pg->d_minv, pg->d_hs,
                            lambda, pg->n_poses, active_edges, pg->d_r, pg->d_r + N6, pg->d_z, pg->d_z + N6, pg->d_partials,
                            pg->d_pose, pg->d_fixed, xc, agg, pc_tail);
-        hipLaunchKernelGGL(nos::pgo_cg_direction_dev_kernel, dim3(vblocks), dim3(256), 0, slot.stream, n, pg->d_scalars,
-                           pg->d_z, pg->d_p);
+        if (!fuse_direction)
+          hipLaunchKernelGGL(nos::pgo_cg_direction_dev_kernel, dim3(vblocks), dim3(256), 0, slot.stream, n, pg->d_scalars,
+                             pg->d_z, pg->d_p);
         NOS_HIP_CHECK(hipGetLastError());
       }
       it += batch;
@@ -490,6 +684,9 @@ int nos_pgo_retract(nos_pose_graph* pg) {
   const uint32_t N = pg->n_poses;
   hipLaunchKernelGGL(nos::pgo_retract_kernel, dim3((N + pg->n_edges + 255) / 256), dim3(256), 0, slot.stream, N, pg->n_edges,
                      pg->d_fixed, pg->d_sw_free, pg->d_x, pg->d_x + size_t(6) * N, pg->d_pose, pg->d_edge);
+  if (pg->block_poses != 0 && pg->n_free_switches > 0)  // the block entries carry their own copy of the constraint records
+    hipLaunchKernelGGL(nos::pgo_refresh_entries_kernel, dim3((pg->n_entries + 255) / 256), dim3(256), 0, slot.stream,
+                       pg->n_entries, pg->d_bent_edge, pg->d_edge, pg->d_bent);
   NOS_HIP_CHECK(hipGetLastError());
   NOS_HIP_CHECK(hipStreamSynchronize(slot.stream));
   return NOS_OK;
@@ -542,18 +739,17 @@ int nos_pgo_time_sweep(nos_pose_graph* pg, int which, double lambda, int repeats
   if (!pg || !ms_per_sweep || repeats < 1 || which < 0 || which > 1) return fail(NOS_ERR_INVALID_ARGUMENT, "bad argument");
   DeviceSlot& slot = pg->ctx->slots[0];
   NOS_HIP_CHECK(hipSetDevice(slot.device));
-  const size_t N6 = size_t(6) * pg->n_poses;
   const uint32_t pose_blocks = (pg->n_poses + 255) / 256;
-  const uint32_t mv_blocks = pose_blocks + (pg->n_free_switches > 0 ? (pg->n_edges + 255) / 256 : 0u);
-  const nos::PgoTail mv_tail{pg->d_partials, pg->d_tickets, pg->d_scalars};
-  if (which == 0) {  // x = gradient (its switch rows included)
+  if (which == 0) {  // x = gradient (its switch rows included); CG scalars zeroed: beta = 0, no breakdown flag
     NOS_HIP_CHECK(hipMemcpyAsync(pg->d_p, pg->d_grad, pg->n_unknowns * sizeof(double), hipMemcpyDeviceToDevice, slot.stream));
-    (void)N6;
+    NOS_HIP_CHECK(hipMemsetAsync(pg->d_scalars, 0, 8 * sizeof(double), slot.stream));
   }
   auto sweep = [&]() {
-    if (which == 0) {
-      hipLaunchKernelGGL(nos::pgo_matvec_cg_kernel, dim3(mv_blocks), dim3(256), 0, slot.stream, pg->view, pg->d_hdiag, pg->d_hs,
-                         lambda, pg->d_p, pg->d_ap, pose_blocks, mv_tail);
+    if (which == 0) {  // as the PCG iteration launches it: with the direction update in its staging where that form exists
+      if (pg->block_poses != 0)
+        (void)pgo_launch_product(pg, lambda, pg->d_p, pg->d_ap, pg->d_grad, pg->d_p2);
+      else
+        (void)pgo_launch_product(pg, lambda, pg->d_p, pg->d_ap);
     } else {
       hipLaunchKernelGGL(nos::pgo_linearize_kernel, dim3(pose_blocks), dim3(256), 0, slot.stream, pg->view, pg->d_hdiag,
                          pg->d_grad, pg->d_partials);
@@ -587,7 +783,7 @@ int nos_pgo_matvec(nos_pose_graph* pg, double lambda, const double* x, double* y
   for (size_t e = 0; e < pg->n_edges; ++e) rec[6 * N + e] = x[6 * N + e];
   NOS_HIP_CHECK(hipMemcpyAsync(pg->d_p, rec.data(), n * sizeof(double), hipMemcpyHostToDevice, slot.stream));
   NOS_HIP_CHECK(hipMemsetAsync(pg->d_ap, 0, n * sizeof(double), slot.stream));
-  int rc = pgo_matvec(pg, lambda, pg->d_p, pg->d_ap, nullptr);
+  int rc = pgo_launch_product(pg, lambda, pg->d_p, pg->d_ap);  // the product the PCG iteration makes
   if (rc != NOS_OK) return rc;
   NOS_HIP_CHECK(hipMemcpyAsync(rec.data(), pg->d_ap, n * sizeof(double), hipMemcpyDeviceToHost, slot.stream));
   NOS_HIP_CHECK(hipStreamSynchronize(slot.stream));

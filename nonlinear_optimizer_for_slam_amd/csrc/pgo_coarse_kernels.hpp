@@ -254,6 +254,157 @@ __global__ __launch_bounds__(128) void pgo_coarse_scatter_kernel(uint32_t n_agg,
   for (int r = 0; r < 6; ++r) dst[size_t(36) * J + 6 * r + dof] = rc[size_t(6) * J + r];
 }
 
+// ---- the coarse operator assembled directly (round 4; replaces the 18 probing products per solve)
+//
+// A_c(I, J) = Σ_{i in I} Σ_{j in J} B_iᵀ H'_ij B_j with H'_ii = Σ_e s² J_iᵀ J_i + λ diag(H_ii), H'_ij = Σ_e s² J_iᵀ J_j for the
+// constraints e = (i, j) whose ends lie at most one aggregate apart and are both free.  With B = [I X; 0 Rᵀ] (X = −[p − c]x)
+// and the constraint Jacobians J_ref = [−I A; 0 B_m], J_qry = [I 0; 0 C] the product W = J B is again [σ I, P; 0, Q]:
+//     reference end: σ = −1, P = −X + A Rᵀ, Q = B_m Rᵀ          query end: σ = +1, P = X, Q = C Rᵀ
+// and W_iᵀ W_j = [σ_i σ_j I, σ_i P_j; σ_j P_iᵀ, P_iᵀ P_j + Q_iᵀ Q_j] — one scalar and three 3x3 blocks (28 numbers).
+// Owner computes, like every other sweep: one wave per aggregate, lane ↔ pose, each lane walks its pose's constraints in
+// adjacency order, the 28 sums go through the fixed butterfly.  WHICH = 0: A_c(I, I); 1: A_c(I, I−1); 2: A_c(I, I+1) —
+// three launches of one sweep each instead of 18 probing products (each a full matrix-free product plus three small kernels).
+struct CoarseW {
+  double sigma, P[9], Q[9];
+};
+
+__device__ __forceinline__ void coarse_w(const EdgeTerms& T, int role, const double (&d)[3], const double (&R)[9], CoarseW& W) {
+  // X = −[d]x = [0 dz −dy; −dz 0 dx; dy −dx 0];  Rt = Rᵀ
+  const double X[9] = {0.0, d[2], -d[1], -d[2], 0.0, d[0], d[1], -d[0], 0.0};
+  if (role == 0) {
+    W.sigma = -1.0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        // (A Rᵀ)(r, c) = Σ_k A(r, k) R(c, k)
+        W.P[3 * r + c] = -X[3 * r + c] + (T.A[3 * r] * R[3 * c] + T.A[3 * r + 1] * R[3 * c + 1] + T.A[3 * r + 2] * R[3 * c + 2]);
+        W.Q[3 * r + c] = T.B[3 * r] * R[3 * c] + T.B[3 * r + 1] * R[3 * c + 1] + T.B[3 * r + 2] * R[3 * c + 2];
+      }
+  } else {
+    W.sigma = 1.0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        W.P[3 * r + c] = X[3 * r + c];
+        W.Q[3 * r + c] = T.C[3 * r] * R[3 * c] + T.C[3 * r + 1] * R[3 * c + 1] + T.C[3 * r + 2] * R[3 * c + 2];
+      }
+  }
+}
+
+// acc (28) += w · Wiᵀ Wj:  [0] the scalar of the top-left block, [1..9] top-right, [10..18] bottom-left, [19..27] bottom-right
+__device__ __forceinline__ void coarse_accumulate(double w, const CoarseW& Wi, const CoarseW& Wj, double (&acc)[28]) {
+  acc[0] += w * (Wi.sigma * Wj.sigma);
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      acc[1 + 3 * r + c] += w * (Wi.sigma * Wj.P[3 * r + c]);
+      acc[10 + 3 * r + c] += w * (Wj.sigma * Wi.P[3 * c + r]);
+      double v = 0.0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) v += Wi.P[3 * k + r] * Wj.P[3 * k + c] + Wi.Q[3 * k + r] * Wj.Q[3 * k + c];
+      acc[19 + 3 * r + c] += w * v;
+    }
+}
+
+template <int WHICH>
+__global__ __launch_bounds__(256) void pgo_coarse_assemble_kernel(PgoView G, const double* __restrict__ hdiag, double lambda,
+                                                                  uint32_t agg, uint32_t n_agg, double* __restrict__ out) {
+  const uint32_t I = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t lane = threadIdx.x & 63u;
+  if (I >= n_agg) return;  // wave-uniform
+  if ((WHICH == 1 && I == 0) || (WHICH == 2 && I + 1 >= n_agg)) {  // no such neighbour: the block is zero
+    if (lane < 36) out[size_t(36) * I + lane] = 0.0;
+    return;
+  }
+  double acc[28];
+#pragma unroll
+  for (int k = 0; k < 28; ++k) acc[k] = 0.0;
+  const uint32_t lo = I * agg, hi = (lo + agg < G.n_poses) ? lo + agg : G.n_poses;
+  const uint32_t want = WHICH == 0 ? I : (WHICH == 1 ? I - 1 : I + 1);  // aggregate of the neighbour whose coupling is summed
+  double pc[8];
+  load_record(G.pose, lo, pc);
+  for (uint32_t i = lo + lane; i < hi; i += 64u) {
+    if (G.fixed[i]) continue;  // B_i = 0
+    double pi[8], Ri[9];
+    load_record(G.pose, i, pi);
+    qrot_matrix(Quat4{pi[3], pi[4], pi[5], pi[6]}, Ri);
+    const double di[3] = {pi[0] - pc[0], pi[1] - pc[1], pi[2] - pc[2]};
+    if (WHICH == 0) {  // damping: B_iᵀ λ diag(H_ii) B_i = [Dt, Dt X; Xᵀ Dt, Xᵀ Dt X + R Dr Rᵀ]
+      const int dg[6] = {0, 6, 11, 15, 18, 20};
+      double h[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) h[k] = lambda * hdiag[size_t(dg[k]) * G.n_poses + i];
+      const double X[9] = {0.0, di[2], -di[1], -di[2], 0.0, di[0], di[1], -di[0], 0.0};
+      // the top-left block is diag(h_t), not a multiple of I: it is kept in the three diagonal slots of a 3x3 by folding
+      // it into the accumulators after the wave sum is impossible — so the damping goes through its own small block below
+      // (dt[3]) and is added at the store
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          acc[1 + 3 * r + c] += h[r] * X[3 * r + c];
+          acc[10 + 3 * r + c] += X[3 * c + r] * h[c];
+          double v = 0.0;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) v += X[3 * k + r] * h[k] * X[3 * k + c] + Ri[3 * r + k] * h[3 + k] * Ri[3 * c + k];
+          acc[19 + 3 * r + c] += v;
+        }
+    }
+    for (uint32_t a = G.adj_off[i]; a < G.adj_off[i + 1]; ++a) {
+      const uint32_t e = G.adj[a] >> 1;
+      const int role = int(G.adj[a] & 1u);
+      const uint32_t j = G.adj_nbr[a];
+      const uint32_t aj = j / agg;
+      const bool cross = !G.fixed[j] && aj == want;  // WHICH = 0: the neighbour lies in the same aggregate
+      if (WHICH != 0 && !cross) continue;
+      EdgeTerms T;
+      const double s = edge_terms(G, e, role == 0 ? i : j, role == 0 ? j : i, T);
+      CoarseW Wi;
+      coarse_w(T, role, di, Ri, Wi);
+      if (WHICH == 0) coarse_accumulate(s * s, Wi, Wi, acc);
+      if (cross) {
+        double pj[8], pcj[8], Rj[9];
+        load_record(G.pose, j, pj);
+        load_record(G.pose, size_t(aj) * agg, pcj);
+        qrot_matrix(Quat4{pj[3], pj[4], pj[5], pj[6]}, Rj);
+        const double dj[3] = {pj[0] - pcj[0], pj[1] - pcj[1], pj[2] - pcj[2]};
+        CoarseW Wj;
+        coarse_w(T, 1 - role, dj, Rj, Wj);
+        coarse_accumulate(s * s, Wi, Wj, acc);
+      }
+    }
+  }
+  // the damping's top-left block diag(lambda h_t) is not a multiple of the identity: its three numbers travel separately
+  double dt[3] = {0.0, 0.0, 0.0};
+  if (WHICH == 0) {
+    for (uint32_t i = lo + lane; i < hi; i += 64u) {
+      if (G.fixed[i]) continue;
+      dt[0] += lambda * hdiag[size_t(0) * G.n_poses + i];
+      dt[1] += lambda * hdiag[size_t(6) * G.n_poses + i];
+      dt[2] += lambda * hdiag[size_t(11) * G.n_poses + i];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 28; ++k) acc[k] = wave_sum(acc[k]);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) dt[k] = wave_sum(dt[k]);
+  if (lane != 0) return;
+  double M[36];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      M[6 * r + c] = r == c ? acc[0] + dt[r] : 0.0;
+      M[6 * r + 3 + c] = acc[1 + 3 * r + c];
+      M[6 * (3 + r) + c] = acc[10 + 3 * r + c];
+      M[6 * (3 + r) + 3 + c] = acc[19 + 3 * r + c];
+    }
+  m6_store(out + size_t(36) * I, M);
+}
+
 // Make the probed operator exactly symmetric (D ← (D + Dᵀ)/2, L_J ← (L_J + U_{J−1}ᵀ)/2, U_{J−1} ← L_Jᵀ) and give
 // aggregates without a free pose an identity block.
 __global__ __launch_bounds__(128) void pgo_coarse_symmetrize_kernel(uint32_t n_agg, double* __restrict__ L,
@@ -299,6 +450,26 @@ __global__ __launch_bounds__(128) void pgo_coarse_symmetrize_kernel(uint32_t n_a
   }
 }
 
+// Storage of the per-level elimination factors alpha / gamma (36 doubles per row and level each).  They are only ever read
+// by pgo_pcr_span_kernel, whose lanes walk the rows of ONE residue class J ≡ c (mod 2^shift) in order, so the factors of a
+// level are kept as 36 planes over a class-major row index: plane k of level l at (l·36 + k)·pitch + slot(J),
+//     slot(J) = (J mod 2^shift)·rows + (J >> shift),    rows = ceil(n_agg / 2^shift),   pitch >= 2^shift · rows
+// (shift = first level of the span the level belongs to; shift = 0: slot = J).  A wave then reads 64 consecutive doubles per
+// load instruction; the row-major [J][36] storage of round 3 made every load instruction touch 64 cache lines.
+struct PcrLevelLayout {
+  uint32_t shift, rows;
+  __host__ __device__ size_t slot(uint32_t J) const { return size_t(J & ((1u << shift) - 1u)) * rows + (J >> shift); }
+};
+
+__device__ __forceinline__ void m6_store_planes(double* __restrict__ p, size_t pitch, const double (&A)[36]) {
+#pragma unroll
+  for (int k = 0; k < 36; ++k) p[size_t(k) * pitch] = A[k];
+}
+__device__ __forceinline__ void m6_load_planes(const double* __restrict__ p, size_t pitch, double (&A)[36]) {
+#pragma unroll
+  for (int k = 0; k < 36; ++k) A[k] = p[size_t(k) * pitch];
+}
+
 // One level of parallel cyclic reduction with stride d: row J is combined with rows J − d and J + d,
 //   alpha = −L_J D_{J−d}⁻¹,  gamma = −U_J D_{J+d}⁻¹,
 //   L'_J = alpha L_{J−d},  D'_J = D_J + alpha U_{J−d} + gamma L_{J+d},  U'_J = gamma U_{J+d};
@@ -307,7 +478,8 @@ __global__ __launch_bounds__(128) void pgo_pcr_setup_kernel(uint32_t n_agg, uint
                                                             const double* __restrict__ Din, const double* __restrict__ Uin,
                                                             double* __restrict__ Lout, double* __restrict__ Dout,
                                                             double* __restrict__ Uout, double* __restrict__ alpha,
-                                                            double* __restrict__ gamma) {
+                                                            double* __restrict__ gamma, PcrLevelLayout lay, size_t pitch) {
+  // alpha / gamma: the planes of THIS level (see PcrLevelLayout)
   const uint32_t J = blockIdx.x * 128 + threadIdx.x;
   if (J >= n_agg) return;
   double Dn[36], Ln[36], Un[36], a[36], g[36], t[36], inv[36], blk[36];
@@ -350,8 +522,8 @@ __global__ __launch_bounds__(128) void pgo_pcr_setup_kernel(uint32_t n_agg, uint
   m6_store(Lout + size_t(36) * J, Ln);
   m6_store(Dout + size_t(36) * J, Dn);
   m6_store(Uout + size_t(36) * J, Un);
-  m6_store(alpha + size_t(36) * J, a);
-  m6_store(gamma + size_t(36) * J, g);
+  m6_store_planes(alpha + lay.slot(J), pitch, a);
+  m6_store_planes(gamma + lay.slot(J), pitch, g);
 }
 
 // Inverse of the decoupled diagonal blocks after the last level.
@@ -365,90 +537,59 @@ __global__ __launch_bounds__(128) void pgo_pcr_finish_kernel(uint32_t n_agg, con
   m6_store(Dinv + size_t(36) * J, inv);
 }
 
-// Right-hand side of one level: b'_J = b_J + alpha_J b_{J−d} + gamma_J b_{J+d}.
-__global__ __launch_bounds__(128) void pgo_pcr_apply_kernel(uint32_t n_agg, uint32_t d, const double* __restrict__ alpha,
-                                                            const double* __restrict__ gamma, const double* __restrict__ bin,
-                                                            double* __restrict__ bout) {
-  const uint32_t J = blockIdx.x * 128 + threadIdx.x;
-  if (J >= n_agg) return;
-  double b[6], x[6], m[36];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) b[k] = bin[size_t(6) * J + k];
-  if (J >= d) {
-#pragma unroll
-    for (int k = 0; k < 6; ++k) x[k] = bin[size_t(6) * (J - d) + k];
-    m6_load(alpha + size_t(36) * J, m);
-    m6_mulvec_add(m, x, b);
-  }
-  if (J + d < n_agg) {
-#pragma unroll
-    for (int k = 0; k < 6; ++k) x[k] = bin[size_t(6) * (J + d) + k];
-    m6_load(gamma + size_t(36) * J, m);
-    m6_mulvec_add(m, x, b);
-  }
-#pragma unroll
-  for (int k = 0; k < 6; ++k) bout[size_t(6) * J + k] = b[k];
-}
-
-// x_J = D_J⁻¹ b_J
-__global__ __launch_bounds__(128) void pgo_pcr_solve_kernel(uint32_t n_agg, const double* __restrict__ Dinv,
-                                                            const double* __restrict__ b, double* __restrict__ x) {
-  const uint32_t J = blockIdx.x * 128 + threadIdx.x;
-  if (J >= n_agg) return;
-  double m[36], bi[6], xi[6] = {0, 0, 0, 0, 0, 0};
-  m6_load(Dinv + size_t(36) * J, m);
-#pragma unroll
-  for (int k = 0; k < 6; ++k) bi[k] = b[size_t(6) * J + k];
-  m6_mulvec_add(m, bi, xi);
-#pragma unroll
-  for (int k = 0; k < 6; ++k) x[size_t(6) * J + k] = xi[k];
-}
-
-// Several PCR levels of the right-hand side in ONE launch (pgo_pcr_apply_kernel needs one launch per level: 15 at 1 M
-// poses, each a few µs of work behind a kernel boundary).  Level l couples row J with rows J ± 2^l only, so after the levels
-// [0, l0) the rows fall into 2^l0 independent residue classes J ≡ c (mod 2^l0); a workgroup takes T consecutive rows of one
-// class (position m ↔ row c + m 2^l0), keeps the right-hand side in LDS (ping-pong) and runs the levels [l0, l1):
+// Several PCR levels of the right-hand side in ONE launch (round 3: one launch per level — 15 at 1 M poses, each a few µs
+// of work behind a kernel boundary — plus one for the block solves).  Level l couples row J with rows J ± 2^l only, so after
+// the levels [0, l0) the rows fall into 2^l0 independent residue classes J ≡ c (mod 2^l0); a workgroup takes T consecutive
+// rows of one class (position m ↔ row c + m 2^l0), keeps the right-hand side in LDS (ping-pong) and runs the levels
+// [l0, l1):   b'_J = b_J + alpha_J b_{J−d} + gamma_J b_{J+d},  d = 2^l
+// What bounds it is what ONE CU can load (a level is 576 bytes of factors per row; ≈ 30 GB/s per CU, measured 7.5 µs per
+// level with 512 rows per workgroup on 81 CUs): small workgroups (T = 128), few levels per span (4: halo 15) → every span
+// runs on 200+ CUs.
 //   * halo > 0: the T positions include `halo` = 2^(l1-l0) - 1 positions on either side whose values go wrong level by
 //     level (their own neighbours are outside the workgroup) and are dropped: T - 2 halo positions are written;
-//   * halo = 0: the whole class fits the workgroup (rows_per_class <= T): no position is dropped, and with Dinv != nullptr
-//     the decoupled blocks are solved in the same launch (pgo_pcr_solve_kernel's x_J = D_J^-1 b_J).
-// Every row's arithmetic is that of pgo_pcr_apply_kernel, level by level: same bits.
+//   * halo = 0: the whole class fits the workgroup (rows of a class <= T): no position is dropped, and with Dinv != nullptr
+//     the decoupled blocks are solved in the same launch (x_J = D_J^-1 b_J).
+// The factors of the NEXT level are requested as soon as the current ones have been used, so their latency overlaps the LDS
+// exchange and the barrier; the loads sit behind no branch (a level index past the span re-reads the last level).
 template <int T>
 __global__ __launch_bounds__(T) void pgo_pcr_span_kernel(uint32_t n_agg, uint32_t l0, uint32_t l1, uint32_t halo,
                                                          const double* __restrict__ alpha, const double* __restrict__ gamma,
-                                                         const double* __restrict__ Dinv, const double* __restrict__ bin,
-                                                         double* __restrict__ bout) {
-  __shared__ double lds[2][T][6];
+                                                         size_t pitch, PcrLevelLayout lay, const double* __restrict__ Dinv,
+                                                         const double* __restrict__ bin, double* __restrict__ bout) {
+  // (the right-hand side of a level is exchanged through LDS as 6 planes of T doubles: conflict-free 8-byte accesses)
+  __shared__ double lds[2][6][T];
   const uint32_t cls = blockIdx.x & ((1u << l0) - 1u), chunk = blockIdx.x >> l0;
   const int tid = int(threadIdx.x);
   const long long m = (long long)chunk * (T - 2 * int(halo)) + tid - int(halo);  // position inside the class
   const long long J = (long long)cls + m * (1ll << l0);
   const bool exists = m >= 0 && J < (long long)n_agg;
+  const size_t slot = lay.slot(exists ? uint32_t(J) : 0u);  // a lane without a row reads row 0's factors and drops them
   double b[6];
 #pragma unroll
   for (int k = 0; k < 6; ++k) b[k] = exists ? bin[size_t(6) * size_t(J) + k] : 0.0;
+  double fa[36], fg[36];
+  if (l0 < l1) {
+    m6_load_planes(alpha + size_t(l0) * 36 * pitch + slot, pitch, fa);
+    m6_load_planes(gamma + size_t(l0) * 36 * pitch + slot, pitch, fg);
+  }
   int cur = 0;
   for (uint32_t l = l0; l < l1; ++l) {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) lds[cur][tid][k] = b[k];
+    for (int k = 0; k < 6; ++k) lds[cur][k][tid] = b[k];
     __syncthreads();
     const long long d = 1ll << l;
     const int dm = 1 << (l - l0);
-    if (exists) {
-      double xn[6], mat[36];
-      if (J >= d) {
+    const uint32_t ln = l + 1 < l1 ? l + 1 : l;
+    double xl[6], xr[6];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) xn[k] = tid - dm >= 0 ? lds[cur][tid - dm][k] : 0.0;
-        m6_load(alpha + (size_t(l) * n_agg + size_t(J)) * 36, mat);
-        m6_mulvec_add(mat, xn, b);
-      }
-      if (J + d < (long long)n_agg) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) xn[k] = tid + dm < T ? lds[cur][tid + dm][k] : 0.0;
-        m6_load(gamma + (size_t(l) * n_agg + size_t(J)) * 36, mat);
-        m6_mulvec_add(mat, xn, b);
-      }
+    for (int k = 0; k < 6; ++k) {
+      xl[k] = tid - dm >= 0 ? lds[cur][k][tid - dm] : 0.0;
+      xr[k] = tid + dm < T ? lds[cur][k][tid + dm] : 0.0;
     }
+    if (exists && J >= d) m6_mulvec_add(fa, xl, b);
+    m6_load_planes(alpha + size_t(ln) * 36 * pitch + slot, pitch, fa);
+    if (exists && J + d < (long long)n_agg) m6_mulvec_add(fg, xr, b);
+    m6_load_planes(gamma + size_t(ln) * 36 * pitch + slot, pitch, fg);
     cur ^= 1;
   }
   if (!exists || tid < int(halo) || tid >= T - int(halo)) return;

@@ -94,12 +94,21 @@ __device__ __forceinline__ void load_record(const double* base, size_t index, do
   }
 }
 
-// Terms of constraint e given the records of its two ends (ir = reference pose, iq = query pose).
+// Terms of a constraint given the 64-byte records of its two ends (pr = reference pose, pq = query pose) and its own.
+__device__ __forceinline__ double edge_terms_rec(const double (&pr)[8], const double (&pq)[8], const double (&ed)[8],
+                                                 EdgeTerms& T);
+
+// Terms of constraint e, records gathered from global memory (ir = reference pose, iq = query pose).
 __device__ __forceinline__ double edge_terms(const PgoView& G, uint32_t e, uint32_t ir, uint32_t iq, EdgeTerms& T) {
   double pr[8], pq[8], ed[8];
   load_record(G.pose, ir, pr);
   load_record(G.pose, iq, pq);
   load_record(G.edge, e, ed);
+  return edge_terms_rec(pr, pq, ed, T);
+}
+
+__device__ __forceinline__ double edge_terms_rec(const double (&pr)[8], const double (&pq)[8], const double (&ed)[8],
+                                                 EdgeTerms& T) {
   const Quat4 qr{pr[3], pr[4], pr[5], pr[6]};
   const Quat4 qq{pq[3], pq[4], pq[5], pq[6]};
   const Quat4 qm{ed[3], ed[4], ed[5], ed[6]};
@@ -270,30 +279,54 @@ __global__ __launch_bounds__(256) void pgo_switch_linearize_kernel(PgoView G, do
 // (rows t + 4096 k, + 1024, + 2048, + 3072; the ≤ 3 left-over rows go into the first), combines them as (s0 + s1) + (s2 + s3),
 // and the 1024 lane values are folded by halving (lane t += lane t + o, o = 512 … 1).  NT threads (1024, or 256 when the
 // sum runs in the tail of a sweep kernel) play the 1024 lanes, so the stand-alone kernel and the in-launch tails give the
-// same bits.  `lds` holds 1024 doubles.  The result is returned to thread 0 only.
-template <int NT>
-__device__ __forceinline__ double pgo_sum_rows(const double* __restrict__ partials, uint32_t count, int width, int w,
-                                               double* __restrict__ lds) {
+// same bits.  The result is returned to thread 0 only.
+template <int NT, int WIDTH>
+__device__ __forceinline__ void pgo_sum_rows(const double* __restrict__ partials, uint32_t count, double* __restrict__ lds,
+                                             double (&total)[WIDTH]) {
+  // lds: WIDTH x 1024 doubles.  All WIDTH columns go through the loads and the fold together (one pass, one set of barriers)
   for (uint32_t t = threadIdx.x; t < 1024u; t += NT) {
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    double s0[WIDTH], s1[WIDTH], s2[WIDTH], s3[WIDTH];
+#pragma unroll
+    for (int w = 0; w < WIDTH; ++w) s0[w] = s1[w] = s2[w] = s3[w] = 0.0;
     uint32_t i = t;
     for (; i + 3 * 1024 < count; i += 4 * 1024) {
-      s0 += partials[size_t(i) * width + w];
-      s1 += partials[size_t(i + 1024) * width + w];
-      s2 += partials[size_t(i + 2 * 1024) * width + w];
-      s3 += partials[size_t(i + 3 * 1024) * width + w];
+#pragma unroll
+      for (int w = 0; w < WIDTH; ++w) {
+        s0[w] += partials[size_t(i) * WIDTH + w];
+        s1[w] += partials[size_t(i + 1024) * WIDTH + w];
+        s2[w] += partials[size_t(i + 2 * 1024) * WIDTH + w];
+        s3[w] += partials[size_t(i + 3 * 1024) * WIDTH + w];
+      }
     }
-    for (; i < count; i += 1024) s0 += partials[size_t(i) * width + w];
-    lds[t] = (s0 + s1) + (s2 + s3);
+    for (; i < count; i += 1024) {
+#pragma unroll
+      for (int w = 0; w < WIDTH; ++w) s0[w] += partials[size_t(i) * WIDTH + w];
+    }
+#pragma unroll
+    for (int w = 0; w < WIDTH; ++w) lds[w * 1024 + t] = (s0[w] + s1[w]) + (s2[w] + s3[w]);
   }
   __syncthreads();
-  for (int o = 512; o > 0; o >>= 1) {
-    for (int t = int(threadIdx.x); t < o; t += NT) lds[t] += lds[t + o];
+  for (int o = 512; o >= 64; o >>= 1) {
+    for (int t = int(threadIdx.x); t < o; t += NT) {
+#pragma unroll
+      for (int w = 0; w < WIDTH; ++w) lds[w * 1024 + t] += lds[w * 1024 + t + o];
+    }
     __syncthreads();
   }
-  const double total = lds[0];
+  // lanes t < o of the last six levels are the lanes of one wave: the same additions through shuffles, no barriers
+  if (threadIdx.x < 64) {
+#pragma unroll
+    for (int w = 0; w < WIDTH; ++w) {
+      double v = lds[w * 1024 + threadIdx.x];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const double u = __shfl_down(v, o, kWave);
+        if (int(threadIdx.x) < o) v += u;
+      }
+      total[w] = v;
+    }
+  }
   __syncthreads();
-  return total;
 }
 
 // In-launch tail of a sweep whose workgroups each publish `width` partial sums: the workgroup that arrives last adds all
@@ -495,11 +528,241 @@ __global__ __launch_bounds__(256) void pgo_matvec_cg_kernel(PgoView G, const dou
     pgo_publish_partials<1>(tail, v);
   }
   if (!pgo_tail_is_last(tail, &last_flag)) return;
-  const double total = pgo_sum_rows<256>(tail.partials, gridDim.x, 1, 0, lds);
+  double total[1];
+  pgo_sum_rows<256, 1>(tail.partials, gridDim.x, lds, total);
   if (threadIdx.x == 0) {
-    tail.scalars[0] = total;
+    tail.scalars[0] = total[0];
     pgo_cg_alpha(tail.scalars);
   }
+}
+
+// ---- block-local product (round 4)
+//
+// What the counters say about the owner-computes product above (profiles/r04pre_pgo_summary.json): 329 µs, 1.0-2.0 GB of
+// L2-miss traffic for ≈ 0.53 GB of distinct bytes, L2 hit rate 0.41, vector ALUs 11 % busy — every constraint is gathered
+// and its Jacobian blocks re-derived TWICE (once by the lane of either end), and the second visit comes long after the first
+// has left the XCD's 4 MB L2 (the workgroups resident on an XCD touch ≈ 40 MB).  The block-local form visits every
+// constraint once per workgroup:
+//   * the poses are cut into blocks of P consecutive indices, one workgroup each; at creation every block gets the list of
+//     the constraints that touch it ("entries", 80-byte records: the constraint's own 64 bytes + its id, its two pose ids and
+//     the two adjacency slots it feeds; pose ids LOCAL to the block: own pose or halo index), in constraint order — a block's entries are ONE contiguous, coalesced stream, and a
+//     constraint whose ends lie in two blocks is listed in both (16 % of the constraints at P = 128 on a trajectory graph);
+//   * phase A, one lane per entry: the block's own poses and vector entries come from LDS (staged once, coalesced), poses
+//     of other blocks from global memory; residual and Jacobian blocks once, v = s (J_r x_r + J_q x_q) + r x_s, and the two
+//     6-vectors s J_r^T v, s J_q^T v go to the LDS slots of the two adjacency positions (switch rows: computed here too, by
+//     the block that owns the reference end);
+//   * phase B, one lane per pose: its slots are added up in adjacency order — the order the owner-computes sweep uses, so
+//     the result is deterministic and differs from it only by the rounding of s J^T v (formed before the sum instead of
+//     fused into it) — plus the damping term; block partials of x.y, and the in-launch tail of pgo_matvec_cg_kernel.
+// Graphs whose blocks need more LDS slots than fit (hub poses) keep the owner-computes kernels (nos_pgo_create decides).
+struct PgoBlockView {
+  const double* entries;        // [n_entries][10]: t_m (3), q_m wxyz (4), switch, {e | ir_local << 32 | iq_local << 48},
+                                //                  {slot_r | slot_q << 16}; *_local: < P = the block's own pose, else P + halo index
+  const uint32_t* entry_off;    // [n_blocks + 1]
+  const uint32_t* halo;         // pose ids of the other blocks' poses a block's entries refer to, block after block, ascending
+  const uint32_t* halo_off;     // [n_blocks + 1]
+  uint32_t n_blocks;
+  uint32_t halo_cap;            // LDS room for halo poses per workgroup (>= halo poses of any block)
+  uint32_t slot_cap;            // LDS contribution slots per workgroup (>= adjacency entries of any block)
+};
+constexpr uint32_t kPgoNoSlot = 0xFFFFu;
+
+// Persistent workgroups: the grid is sized to what is resident (LDS-limited), every workgroup walks pose blocks
+// blockIdx.x, + gridDim.x, … and publishes ONE partial of x.y and draws ONE ticket at its end.  Per block:
+//   staging   own poses + vector entries (coalesced) and the HALO — the other blocks' poses this block's constraints touch,
+//             listed at creation — into LDS; the lane of pose t also requests its six diagonal entries and its adjacency
+//             range now, so that their latency is gone by phase B;
+//   phase A   (above) every operand from LDS or from the entry stream: no dependent global gather left in the loop;
+//   phase B   one lane per pose.
+template <int P, int T>
+__global__ __launch_bounds__(T) void pgo_matvec_block_kernel(PgoView G, PgoBlockView B, const double* __restrict__ hdiag,
+                                                             const double* __restrict__ h_s, double lambda,
+                                                             const double* __restrict__ x, double* __restrict__ y,
+                                                             int switch_rows, PgoTail tail,
+                                                             const double* __restrict__ z = nullptr,
+                                                             double* __restrict__ x_new = nullptr) {
+  // z != nullptr: the PCG's direction update rides in the staging — the vector multiplied is x_new = z + beta x (beta =
+  // scalars[6] of the preconditioner sweep's tail; x untouched after a breakdown, scalars[7]), formed where x is read and
+  // written to x_new by the block that owns the row: the separate p = z + beta p pass (144 MB at 1 M poses) is gone.
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const bool fused = z != nullptr;
+  const double beta = fused ? tail.scalars[6] : 0.0;
+  const bool frozen = fused && tail.scalars[7] != 0.0;
+  auto direction = [&](size_t idx) -> double {
+    const double xv = x[idx];
+    return (!fused || frozen) ? xv : z[idx] + beta * xv;
+  };
+  const uint32_t rows = uint32_t(P) + B.halo_cap;
+  double* pose_s = smem;                  // [P + halo_cap][8]
+  double* x_s = pose_s + size_t(rows) * 8;  // [P + halo_cap][6]
+  double* contrib = x_s + size_t(rows) * 6;  // [slot_cap][6]; re-used by the tail's sum (>= 1024 doubles)
+  const size_t N6 = size_t(6) * G.n_poses;
+  double* ys = y + N6;
+  using V2 = double __attribute__((ext_vector_type(2)));
+  double xy = 0.0;
+  for (uint32_t blk = blockIdx.x; blk < B.n_blocks; blk += gridDim.x) {
+    const uint32_t base = blk * P;
+    const uint32_t n_in = G.n_poses - base < uint32_t(P) ? G.n_poses - base : uint32_t(P);
+    const uint32_t h0 = B.halo_off[blk], n_halo = B.halo_off[blk + 1] - h0;
+    for (uint32_t t = threadIdx.x; t < n_in * 8; t += T) pose_s[t] = G.pose[size_t(8) * base + t];
+    for (uint32_t t = threadIdx.x; t < n_in * 6; t += T) {
+      const double v = direction(size_t(6) * base + t);
+      x_s[t] = v;
+      if (fused) x_new[size_t(6) * base + t] = v;
+    }
+    for (uint32_t t = threadIdx.x; t < n_halo * 8; t += T)
+      pose_s[size_t(P) * 8 + t] = G.pose[size_t(8) * B.halo[h0 + (t >> 3)] + (t & 7u)];
+    for (uint32_t t = threadIdx.x; t < n_halo * 6; t += T)
+      x_s[size_t(P) * 6 + t] = direction(size_t(6) * B.halo[h0 + t / 6u] + t % 6u);
+    // phase B's own-row operands, requested now
+    double hd[6] = {0, 0, 0, 0, 0, 0};
+    uint32_t a_lo = 0, a_hi = 0;
+    const uint32_t a0 = G.adj_off[base];
+    if (threadIdx.x < n_in) {
+      const uint32_t i = base + threadIdx.x;
+      const int dg[6] = {0, 6, 11, 15, 18, 20};
+#pragma unroll
+      for (int m = 0; m < 6; ++m) hd[m] = hdiag[size_t(dg[m]) * G.n_poses + i];
+      a_lo = G.adj_off[i] - a0;
+      a_hi = G.adj_off[i + 1] - a0;
+    }
+    __syncthreads();
+
+    const uint32_t e0 = B.entry_off[blk], n_ent = B.entry_off[blk + 1] - e0;
+    auto load_entry = [&](uint32_t k, double (&rec)[10]) {  // unconditional: an index past the end re-reads the last entry
+      const uint32_t kk = k < n_ent ? k : n_ent - 1;
+      const V2* q = reinterpret_cast<const V2*>(B.entries + size_t(10) * (e0 + kk));
+#pragma unroll
+      for (int m = 0; m < 5; ++m) {
+        const V2 v = q[m];
+        rec[2 * m] = v[0];
+        rec[2 * m + 1] = v[1];
+      }
+    };
+    auto evaluate = [&](const double (&rec)[10]) {
+      const unsigned long long w8 = (unsigned long long)__double_as_longlong(rec[8]), w9 = (unsigned long long)__double_as_longlong(rec[9]);
+      const uint32_t e = uint32_t(w8), lr = uint32_t(w8 >> 32) & 0xFFFFu, lq = uint32_t(w8 >> 48) & 0xFFFFu;
+      const uint32_t slot_r = uint32_t(w9) & 0xFFFFu, slot_q = uint32_t(w9 >> 16) & 0xFFFFu;
+      double pr[8], pq[8], ed[8], xr[6], xq[6];
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        ed[m] = rec[m];
+        pr[m] = pose_s[8 * lr + m];
+        pq[m] = pose_s[8 * lq + m];
+      }
+      // a fixed pose does not move: its vector entries count as zero (pose record element 7 = fixed flag)
+#pragma unroll
+      for (int m = 0; m < 6; ++m) {
+        xr[m] = pr[7] != 0.0 ? 0.0 : x_s[6 * lr + m];
+        xq[m] = pq[7] != 0.0 ? 0.0 : x_s[6 * lq + m];
+      }
+      EdgeTerms Tm;
+      const double s = edge_terms_rec(pr, pq, ed, Tm);
+      double vr[6], vq[6], v[6];
+      apply_J(Tm, 0, xr, vr);
+      apply_J(Tm, 1, xq, vq);
+      const bool free_sw = switch_rows && G.sw_free[e] != 0;
+      const double xs_e = switch_rows ? direction(N6 + e) : 0.0;  // this constraint's switch component of the vector
+      const double xse = free_sw ? xs_e : 0.0;
+#pragma unroll
+      for (int m = 0; m < 6; ++m) v[m] = s * (vr[m] + vq[m]) + Tm.r[m] * xse;
+      if (slot_r != kPgoNoSlot) {
+        double c[6] = {0, 0, 0, 0, 0, 0};
+        add_JT(Tm, 0, v, s, c);
+#pragma unroll
+        for (int m = 0; m < 6; ++m) contrib[6 * slot_r + m] = c[m];
+        if (switch_rows) {  // the switch row of this constraint, by the block that owns its reference end
+          double out;
+          if (free_sw) {
+            double acc = 0.0;
+#pragma unroll
+            for (int m = 0; m < 6; ++m) acc += Tm.r[m] * (s * (vr[m] + vq[m]));
+            out = acc + h_s[e] * (1.0 + lambda) * xs_e;
+          } else {
+            out = (1.0 + lambda) * xs_e;
+          }
+          ys[e] = out;
+          if (fused) x_new[N6 + e] = xs_e;
+          xy += xs_e * out;
+        }
+      }
+      if (slot_q != kPgoNoSlot) {
+        double c[6] = {0, 0, 0, 0, 0, 0};
+        add_JT(Tm, 1, v, s, c);
+#pragma unroll
+        for (int m = 0; m < 6; ++m) contrib[6 * slot_q + m] = c[m];
+      }
+    };
+    // phase A: two named record buffers, the next entry's 80 bytes in flight while the current one is evaluated
+    if (n_ent > 0) {
+      double recA[10], recB[10];
+      uint32_t k = threadIdx.x;
+      load_entry(k, recA);
+      for (; k < n_ent; k += 2 * T) {
+        load_entry(k + T, recB);
+        __builtin_amdgcn_sched_barrier(0);
+        evaluate(recA);
+        __builtin_amdgcn_sched_barrier(0);
+        load_entry(k + 2 * T, recA);
+        __builtin_amdgcn_sched_barrier(0);
+        if (k + T < n_ent) evaluate(recB);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();
+    // phase B: one lane per pose, its slots in adjacency order
+    if (threadIdx.x < n_in) {
+      const uint32_t i = base + threadIdx.x;
+      double xi[6], out[6];
+#pragma unroll
+      for (int m = 0; m < 6; ++m) xi[m] = x_s[6 * threadIdx.x + m];
+      if (pose_s[8 * threadIdx.x + 7] != 0.0) {
+#pragma unroll
+        for (int m = 0; m < 6; ++m) out[m] = (1.0 + lambda) * xi[m];
+      } else {
+#pragma unroll
+        for (int m = 0; m < 6; ++m) out[m] = 0.0;
+        for (uint32_t a = a_lo; a < a_hi; ++a) {
+#pragma unroll
+          for (int m = 0; m < 6; ++m) out[m] += contrib[6 * a + m];
+        }
+#pragma unroll
+        for (int m = 0; m < 6; ++m) out[m] += lambda * hd[m] * xi[m];
+      }
+#pragma unroll
+      for (int m = 0; m < 6; ++m) {
+        y[size_t(6) * i + m] = out[m];
+        xy += xi[m] * out[m];
+      }
+    }
+    __syncthreads();  // the staged rows and the slots are free for the next block (and, after the last one, for the tail)
+  }
+  __shared__ unsigned int last_flag;
+  double* lds = contrib;
+  const double ws = wave_sum(xy);
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = ws;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double bs = 0.0;
+    for (int w = 0; w < T / 64; ++w) bs += lds[w];
+    const double v1[1] = {bs};
+    pgo_publish_partials<1>(tail, v1);
+  }
+  if (!pgo_tail_is_last(tail, &last_flag)) return;
+  double total[1];
+  pgo_sum_rows<T, 1>(tail.partials, gridDim.x, lds, total);
+  if (threadIdx.x == 0) {
+    tail.scalars[0] = total[0];
+    pgo_cg_alpha(tail.scalars);
+  }
+}
+
+// after a retract: the block entries' copies of the switch values follow the constraint records
+__global__ __launch_bounds__(256) void pgo_refresh_entries_kernel(uint32_t n_entries, const uint32_t* __restrict__ entry_edge,
+                                                                  const double* __restrict__ edge, double* __restrict__ entries) {
+  const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= n_entries) return;
+  entries[size_t(10) * k + 7] = edge[size_t(8) * entry_edge[k] + 7];
 }
 
 // Block-Jacobi preconditioner: inverse of the damped 6x6 diagonal block (Cholesky), stored as 21 upper
@@ -638,7 +901,7 @@ __global__ __launch_bounds__(256) void pgo_apply_precond_kernel(const double* __
     rz = rs[e] * v;
     rr = rs[e] * rs[e];
   }
-  __shared__ double lds[1024];
+  __shared__ double lds[2048];
   __shared__ unsigned int last_flag;
   const double a = wave_sum(rz), b = wave_sum(rr);
   if ((threadIdx.x & 63) == 0) {
@@ -657,11 +920,11 @@ __global__ __launch_bounds__(256) void pgo_apply_precond_kernel(const double* __
   // device-resident CG scalars: the last workgroup sums r.z and r.r and computes beta (pgo_cg_beta)
   if (threadIdx.x == 0) pgo_publish_partials<2>(tail, v);
   if (!pgo_tail_is_last(tail, &last_flag)) return;
-  const double rz_total = pgo_sum_rows<256>(tail.partials, gridDim.x, 2, 0, lds);
-  const double rr_total = pgo_sum_rows<256>(tail.partials, gridDim.x, 2, 1, lds);
+  double totals[2];
+  pgo_sum_rows<256, 2>(tail.partials, gridDim.x, lds, totals);
   if (threadIdx.x == 0) {
-    tail.scalars[0] = rz_total;
-    tail.scalars[1] = rr_total;
+    tail.scalars[0] = totals[0];
+    tail.scalars[1] = totals[1];
     pgo_cg_beta(tail.scalars);
   }
 }
@@ -728,10 +991,18 @@ __global__ __launch_bounds__(256) void pgo_cg_direction_dev_kernel(size_t n, con
 
 __global__ __launch_bounds__(1024) void pgo_sum_partials_kernel(const double* __restrict__ partials, uint32_t count,
                                                                 int width, double* __restrict__ out) {
-  __shared__ double lds[1024];
-  for (int w = 0; w < width; ++w) {
-    const double total = pgo_sum_rows<1024>(partials, count, width, w, lds);
-    if (threadIdx.x == 0) out[w] = total;
+  __shared__ double lds[2048];
+  if (width == 1) {
+    double total[1];
+    pgo_sum_rows<1024, 1>(partials, count, lds, total);
+    if (threadIdx.x == 0) out[0] = total[0];
+  } else {  // width 2: r.z and r.r of the preconditioner sweep
+    double total[2];
+    pgo_sum_rows<1024, 2>(partials, count, lds, total);
+    if (threadIdx.x == 0) {
+      out[0] = total[0];
+      out[1] = total[1];
+    }
   }
 }
 

@@ -35,6 +35,9 @@ def scan_to_map(ctx, ndt_map, scan, initial_pose=None, loss=("exponential", 1.0,
 
     on_solve(round, report, n_matches) is called after every inner Solve (e.g. to print the
     reference's `COST: ..., iter: ...` lines)."""
+    if indexed and keep_multiple:
+        raise ValueError("keep_multiple (the tail drop of the reference's classes) is implemented for the flat layout only: "
+                         "a voxel-indexed dataset has no per-match records to clear (nos_dataset_drop_last_matches)")
     pose = Pose() if initial_pose is None else Pose(initial_pose.R, initial_pose.t)
     last = Pose(pose.R, pose.t)
     options = options or Options()
@@ -44,19 +47,21 @@ def scan_to_map(ctx, ndt_map, scan, initial_pose=None, loss=("exponential", 1.0,
     rounds = []
     outer = 0
     for outer in range(max_outer_iterations):
+        n_used = None
         if indexed:
             dataset, n_matches = ndt_map.match_indexed(scan, pose.R, pose.t, 2, dtype, sort_by_voxel=False)
         else:
             dataset, n_matches = ndt_map.match(scan, pose.R, pose.t, 2, dtype)
             if keep_multiple:
-                dataset.drop_last_matches(n_matches % int(keep_multiple))
+                n_used = n_matches - n_matches % int(keep_multiple)
+                dataset.drop_last_matches(n_matches - n_used)
         try:
             if not solver.SolveDataset(options, dataset, pose):
                 raise RuntimeError("SolveDataset failed (status %d)" % solver.report.status)
         finally:
             dataset.close()
-        rounds.append({"matches": n_matches, "iterations": solver.report.iterations,
-                       "printed_cost": solver.report.printed_cost})
+        rounds.append({"matches": n_matches, "used": n_matches if n_used is None else n_used,  # matched / summed by the solve
+                       "iterations": solver.report.iterations, "printed_cost": solver.report.printed_cost})
         if on_solve is not None:
             on_solve(outer, solver.report, n_matches)
         dR = pose.R.T @ last.R                  # optimized_pose.inverse() * last_optimized_pose

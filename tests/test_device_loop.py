@@ -423,6 +423,31 @@ def test_cluster_solve_abort_path_redoes_the_solve_launch_by_launch(ctx):
     ds.close()
 
 
+def test_a_real_give_up_is_remembered_for_a_while_and_reported(ctx):
+    """the give-up LATCH (after a one-launch solve timed out the device goes straight to the launch-per-iteration
+    loop for lm_cluster_retry_ms instead of paying the bounded wait on every solve) and its expiry had no test, because the
+    only give-up hook bypassed it.  debug_cluster_abort = 2 gives up like a real time-out: the solve falls back (reported
+    as report.fallback), the NEXT solve — hook off — does not even try the one-launch form while the latch holds, and tries
+    it again once lm_cluster_retry_ms has passed.  A failed fallback leaves no error text behind a call that returns OK."""
+    import time
+    from nonlinear_optimizer_for_slam_amd import _lib
+    ds = NdtDataset.from_planes(ctx, synth.ndt_planes(30_000, 900), "f64")
+    good = ds.solve6(np.eye(3), np.zeros(3), EXP, max_iterations=40)
+    assert good[2]["launches"] == 1 and not good[2]["fallback"]
+    with ctx.options(lm_cluster_retry_ms=600):
+        with ctx.options(debug_cluster_abort=2):
+            redo = ds.solve6(np.eye(3), np.zeros(3), EXP, max_iterations=40)
+        assert redo[2]["launches"] > 1 and redo[2]["fallback"] and redo[2]["iterations"] == good[2]["iterations"]
+        latched = ds.solve6(np.eye(3), np.zeros(3), EXP, max_iterations=40)   # hook off, latch still holding
+        assert latched[2]["launches"] > 1 and not latched[2]["fallback"]      # went straight to the loop: nothing gave up
+        assert np.array_equal(latched[0], redo[0]) and np.array_equal(latched[1], redo[1])
+        time.sleep(0.7)
+        again = ds.solve6(np.eye(3), np.zeros(3), EXP, max_iterations=40)     # the latch has expired
+        assert again[2]["launches"] == 1 and np.array_equal(again[0], good[0]) and np.array_equal(again[1], good[1])
+    assert _lib.hip_lib().nos_last_error() in (None, b"") or b"refused" not in _lib.hip_lib().nos_last_error()
+    ds.close()
+
+
 # ---------------------------------------------------------------- resident solve: several correspondences per lane
 
 @pytest.mark.parametrize("kind,dtype,n", [
@@ -521,3 +546,85 @@ def test_beyond_the_resident_capacity_the_one_launch_solve_streams_and_agrees_wi
         assert ds2.solve6(np.eye(3), np.zeros(3), EXP, max_iterations=12)[2]["launches"] > 1
         ds2.close()
     ds.close()
+
+
+def _lm_step_cases(dof, rng, count):
+    """Sums (H upper | g | cost) and loop states that drive every branch of the step: well and badly conditioned H,
+    steps below / above the parameter tolerance, gradients below / above the gradient tolerance, cost up and down
+    (λ × 2 / × 0.6, both clamps), last iteration of the budget, an H the damped solve must refuse, NaN sums."""
+    n = dof
+    cases = []
+    for k in range(count):
+        a = rng.standard_normal((n + 2, n)) * 10.0 ** rng.uniform(-2, 2, size=n)
+        H = a.T @ a
+        g = rng.standard_normal(n) * 10.0 ** rng.uniform(-9, 3)
+        cost = float(10.0 ** rng.uniform(-3, 4))
+        kind = k % 8
+        if kind == 5:
+            H = -H  # not positive definite: the damped solve fails
+        if kind == 6:
+            g[rng.integers(n)] = np.nan
+        if kind == 7:
+            g = g * 1e-9  # tiny step: parameter tolerance
+        sums = np.concatenate([H[np.triu_indices(n)], g, [cost]])
+        th = rng.uniform(-np.pi, np.pi)
+        state = np.zeros(22)
+        if dof == 6:
+            q = rng.standard_normal(4)
+            q /= np.linalg.norm(q)
+            w, x, y, z = q
+            state[:9] = [1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                         2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                         2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]
+            state[12:16] = q
+        else:
+            state[:4] = [np.cos(th), -np.sin(th), np.sin(th), np.cos(th)]
+            state[12] = 1.0
+        state[9:12] = rng.standard_normal(3)
+        state[16] = [1e-6, 1e-3, 1e-2, 2.5e-4, 0.0061][k % 5]  # λ incl. both clamp ends
+        state[17] = cost * (0.5 if (k // 2) % 2 else 2.0)  # previous cost below / above
+        state[18] = state[17]
+        budget = 30
+        state[19] = [0, 7, budget - 1][k % 3]
+        state[21] = 1
+        settings = np.array([budget, [1e-7, 0.0, 1e-3][k % 3], [1e-7, 1e-5, 0.0][(k // 3) % 3], k % 2], dtype=np.float64)
+        if settings[3]:
+            state[16] = float(np.float32(state[16]))
+            state[17] = float(np.float32(state[17]))
+        cases.append((sums, settings, state))
+    return cases
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dof", [6, 3])
+def test_device_step_equals_the_host_step_over_a_sweep_of_sums_and_states(ctx, dof):
+    """The single-lane step every device loop form runs (lm_step_kernel → lm_finish_lane, csrc/assemble_loop.hpp) against
+    the host loop's step (nos_host::LmAdvance6 / LmAdvance3, csrc/host/nos_lm.hpp) on the same sums and state.  The two are
+    separate restatements of MDM/mahalanobis_distance_minimizer_analytic.cc:60-120: the device compares squared norms
+    with squared tolerances and uses its own sin/cos series, so decisions (done / ok / iteration / λ / previous cost) must
+    be EQUAL and the pose within 1e-13 — a case whose norm lies within rounding of its tolerance would be allowed to differ,
+    none of the seeded cases does."""
+    import ctypes
+
+    from nonlinear_optimizer_for_slam_amd import _lib
+
+    hip = _lib.load()
+    host = ctypes.CDLL(_lib.LIB_HOST)
+    dp = ctypes.POINTER(ctypes.c_double)
+    host.nos_host_lm_advance.argtypes = [ctypes.c_int, dp, dp, dp]
+    rng = np.random.default_rng(20261005 + dof)
+    flags = {"done": 0, "failed": 0, "up": 0, "down": 0}
+    for sums, settings, state in _lm_step_cases(dof, rng, 240):
+        dev, ref = state.copy(), state.copy()
+        rc = hip.nos_debug_lm_step(ctx._h, dof, sums.ctypes.data_as(dp), settings.ctypes.data_as(dp), dev.ctypes.data_as(dp))
+        assert rc == 0
+        assert host.nos_host_lm_advance(dof, sums.ctypes.data_as(dp), settings.ctypes.data_as(dp), ref.ctypes.data_as(dp)) == 0
+        assert dev[19:22].tolist() == ref[19:22].tolist(), (sums, settings, state, dev, ref)
+        assert dev[16:19].tolist() == ref[16:19].tolist()  # λ, previous cost, cost: same arithmetic, same bits
+        if ref[21]:
+            np.testing.assert_allclose(dev[:16], ref[:16], rtol=0, atol=1e-13)
+        flags["done"] += int(ref[20])
+        flags["failed"] += int(not ref[21])
+        flags["up"] += int(ref[16] > state[16])
+        flags["down"] += int(ref[16] < state[16])
+    assert all(v >= 10 for v in flags.values()), flags  # every branch was exercised

@@ -104,9 +104,12 @@ def test_two_processes_sharing_one_gpu_match_the_single_process_solve(tmp_path):
 
 # ------------------------------------------------------------------ in-launch mailbox all-reduce (nos_ctx_comm_init_shm)
 
-def _mailbox_worker(rank, world, name, n, out_dir, device_memory=False):
+def _mailbox_worker(rank, world, name, n, out_dir, device_memory=False, one_launch=False):
     """One process per rank, all on GPU 0 (a one-GPU box): shard of the correspondences, mailbox communicator,
-    one accumulate and one device-resident solve.  No torch, no RCCL: the exchange happens inside the launches."""
+    one accumulate and one device-resident solve.  No torch, no RCCL: the exchange happens inside the launches.
+    one_launch: the device-memory mailbox's default since round 4 — the whole LM loop in ONE launch per rank, the exchange
+    its third all-reduce stage; every rank gets 256 / world workgroups (all ranks' grids must be resident together on the
+    one GPU they share here).  Otherwise the launch-per-iteration loop (lm_cluster = 0), the form both transports share."""
     import numpy as np
     from nonlinear_optimizer_for_slam_amd import Context, NdtDataset, distributed, synth
     loss = ("exponential", 1.0, 1.0)
@@ -115,6 +118,10 @@ def _mailbox_worker(rank, world, name, n, out_dir, device_memory=False):
     ctx = Context((0,))
     ctx.comm_init_shm(world, rank, name, device_memory=device_memory)
     assert ctx.comm_size == world
+    if one_launch:
+        ctx.set_option("lm_cluster_max_blocks", 256 // world)
+    else:
+        ctx.set_option("lm_cluster", 0)
     ds = NdtDataset.from_planes(ctx, np.ascontiguousarray(planes[:, lo:hi]), "f64")
     probe = ctx.comm_allreduce([rank + 1.0, 1.0])
     R_test = np.array([[0.9987, -0.0499, -0.0199], [0.0501, 0.9987, 0.0095], [0.0194, -0.0105, 0.9998]])
@@ -123,7 +130,8 @@ def _mailbox_worker(rank, world, name, n, out_dir, device_memory=False):
     # a second solve right behind the first: rounds keep alternating across solves and no-op launches
     R2, t2, rep2 = ds.solve6(np.eye(3), np.zeros(3), loss, max_iterations=60, launches_in_flight=7)
     np.savez(os.path.join(out_dir, "mail_rank%d.npz" % rank), probe=probe, out=out, R=R, t=t, it=rep["iterations"],
-             cost=rep["cost_history"], R2=R2, t2=t2, ok=int(rep["ok"] and rep2["ok"]))
+             cost=rep["cost_history"], R2=R2, t2=t2, ok=int(rep["ok"] and rep2["ok"]), launches=rep["launches"],
+             launches2=rep2["launches"], fallback=int(rep["fallback"]) + int(rep2["fallback"]))
     ds.close()
     ctx.close()
 
@@ -175,6 +183,42 @@ def test_mailbox_allreduce_ranks_agree_bitwise_and_match_one_process(tmp_path, w
     assert dt < 1e-10 and dq < 1e-10, (dt, dq)
     ds.close()
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,n", [(2, 90_001), (3, 120_000), (2, 3_000_000)])
+def test_one_launch_loop_with_the_exchange_inside_the_launch(tmp_path, world, n):
+    """Round 4: a rank with a device-memory mailbox communicator keeps the ONE-LAUNCH loop the single-GPU headline runs —
+    the 28 sums of every iteration cross the ranks as a third stage of the in-launch all-reduce (workgroup 0 pushes this
+    GPU's sums into every peer's buffer as tagged 8-byte granules, adds the ranks' sums in rank order, hands the result to
+    the other workgroups).  launches == 1 on every rank, no fallback, identical bits on every rank, and the same solve as
+    the launch-per-iteration mailbox form (the local reduction order differs, so to rounding, not to the bit); the third
+    case streams its data from HBM every iteration (1.5 M correspondences per rank on 128 workgroups)."""
+    import uuid
+    from nonlinear_optimizer_for_slam_amd import api
+    from tests import helpers
+    res = {}
+    for one_launch in (True, False):
+        sub = tmp_path / ("one" if one_launch else "per_iteration")
+        sub.mkdir()
+        name = "/nos_test_%s" % uuid.uuid4().hex
+        try:
+            mp.spawn(_mailbox_worker, args=(world, name, n, str(sub), True, one_launch), nprocs=world, join=True)
+        finally:
+            api.shm_unlink(name)
+        res[one_launch] = [np.load(sub / ("mail_rank%d.npz" % r)) for r in range(world)]
+    one, per = res[True], res[False]
+    for r in one:
+        assert int(r["ok"]) == 1 and int(r["fallback"]) == 0
+        assert int(r["launches"]) == 1 and int(r["launches2"]) == 1
+        for key in ("out", "R", "t", "cost", "R2", "t2"):
+            assert np.array_equal(r[key], one[0][key]), key            # identical bits on every rank
+    assert np.array_equal(one[0]["R"], one[0]["R2"]) and np.array_equal(one[0]["t"], one[0]["t2"])
+    assert int(per[0]["launches"]) > 1
+    assert int(one[0]["it"]) == int(per[0]["it"])
+    dt, dq = helpers.pose_delta(one[0]["R"].reshape(3, 3), one[0]["t"], per[0]["R"].reshape(3, 3), per[0]["t"])
+    assert dt < 1e-11 and dq < 1e-11, (dt, dq)
+    np.testing.assert_allclose(one[0]["cost"], per[0]["cost"], rtol=1e-12)
 
 
 def _mailbox_lonely_worker(rank, name, out_dir):

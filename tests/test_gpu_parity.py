@@ -433,7 +433,7 @@ def test_options_are_range_checked_and_two_contexts_share_a_device(oracle):
     from nonlinear_optimizer_for_slam_amd import _lib
     a = Context((0,))
     for key, bad in (("plane_skew", -5), ("lm_cluster", 9), ("lm_window", 0), ("tile_log2", 3), ("pgo_agg", 1),
-                     ("map_eigen_version", 35), ("debug_cluster_abort", 2), ("nt", -2)):
+                     ("map_eigen_version", 35), ("debug_cluster_abort", 3), ("nt", -2), ("lm_cluster_max_blocks", 0)):
         with pytest.raises(_lib.NosError) as err:
             a.set_option(key, bad)
         assert err.value.status == 1, key

@@ -279,3 +279,74 @@ def test_pcg_with_device_resident_scalars_equals_host_scalar_pcg(ctx):
     np.testing.assert_allclose(gpu.vector("step"), want, rtol=0, atol=1e-8 * np.max(np.abs(want)))
     assert it % 8 == 0 or it == 4000 or res <= 1e-13
     gpu.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_switches", [False, True])
+def test_block_local_product_equals_owner_computes_product(ctx, with_switches):
+    """Round 4's product visits every constraint once per block of 128 poses (entry lists built by nos_pgo_create, the two
+    s J^T v contributions parked in LDS slots and added in adjacency order); round 2's walks every pose's constraints and
+    re-derives each constraint at both ends.  Same sums in the same order — they differ only in where s J^T v is rounded —
+    on a graph whose blocks have boundary constraints, fixed poses and (second case) free switches; a block boundary that
+    falls inside the last, partly filled block is part of the graph size chosen."""
+    from nonlinear_optimizer_for_slam_amd import pgo
+    n = 128 * 9 + 37
+    d = op.random_graph(n, 3, seed=12)
+    m = d["ref"].size
+    fixed = d["fixed"].copy()
+    fixed[[200, 513]] = 1
+    free = init = None
+    if with_switches:
+        free = (np.arange(m) % 3 == 1).astype(np.uint8)
+        init = np.where(free, 0.8, 1.0)
+    rng = np.random.default_rng(3)
+    x = rng.normal(size=6 * n + m)
+    if free is None:
+        x[6 * n:] = 0.0
+    else:
+        x[6 * n:][free == 0] = 0.0
+    for i in np.nonzero(fixed)[0]:
+        x[[k * n + i for k in range(6)]] = 0.0
+    got = {}
+    for block in (1, 0):
+        with ctx.options(pgo_block=block):
+            g = pgo.PoseGraph(ctx, d["init"], d["ref"], d["qry"], d["meas"], init, free, fixed)
+        g.linearize()
+        got[block] = (g.matvec(1e-3, x), g.solve(1e-3, 400, 1e-10), g.vector("step").copy())
+        g.close()
+    y1, y0 = got[1][0], got[0][0]
+    np.testing.assert_allclose(y1, y0, rtol=0, atol=1e-13 * np.max(np.abs(y0)))
+    assert got[1][1][0] == got[0][1][0]                      # PCG iterations
+    np.testing.assert_allclose(got[1][2], got[0][2], rtol=0, atol=1e-9 * np.max(np.abs(got[0][2])))
+
+
+@pytest.mark.gpu
+def test_coarse_operator_assembled_directly_equals_the_probed_one(ctx):
+    """The coarse operator A_c = P^T H' P of the two-level preconditioner: round 2 probed it with 18 masked matrix-free
+    products per solve, round 4 assembles its three block diagonals in three sweeps over the constraints
+    (pgo_coarse_assemble_kernel).  Same operator up to rounding: the PCG needs the same number of iterations and reaches the
+    same step, with loop closures that span many aggregates (dropped from H' in both forms) and fixed poses in the graph."""
+    from nonlinear_optimizer_for_slam_amd import pgo
+    d = op.random_graph(4000, 3, seed=6)
+    rng = np.random.default_rng(1)
+    extra_ref = rng.integers(0, 2000, 30)
+    extra_qry = extra_ref + rng.integers(900, 1900, 30)
+    ref = np.concatenate([d["ref"], extra_ref]).astype(np.int32)
+    qry = np.concatenate([d["qry"], extra_qry]).astype(np.int32)
+    meas = np.concatenate([d["meas"], d["meas"][:30]])
+    fixed = d["fixed"].copy()
+    fixed[[777, 2048]] = 1
+    g = pgo.PoseGraph(ctx, d["init"], ref, qry, meas, None, None, fixed)
+    g.linearize()
+    res = {}
+    for probe in (0, 1):
+        with ctx.options(pgo_coarse_probe=probe):
+            it, rel, _ = g.solve(1e-3, 2000, 1e-11)
+        res[probe] = (it, rel, g.vector("step").copy())
+    assert res[0][1] <= 1e-11 and res[1][1] <= 1e-11
+    assert abs(res[0][0] - res[1][0]) <= 8, (res[0][0], res[1][0])   # the host looks at |r| every 8th iteration
+    np.testing.assert_allclose(res[0][2], res[1][2], rtol=0, atol=1e-7 * np.max(np.abs(res[1][2])))
+    with ctx.options(pgo_precond=0):
+        it_bj, _, _ = g.solve(1e-3, 4000, 1e-11)
+    assert res[0][0] < it_bj                                        # and it is still a preconditioner worth having
+    g.close()

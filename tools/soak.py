@@ -18,7 +18,7 @@ first = {}
 counts = {}
 t_end = time.time() + budget
 R_test = np.array([[0.9987, -0.0499, -0.0199], [0.0501, 0.9987, 0.0095], [0.0194, -0.0105, 0.9998]])
-FORMS = (("default", {}), ("sc1-stage1", {"lm_cluster": 5}), ("counters", {"lm_cluster": 3}),
+FORMS = (("default", {}), ("sc1-stage1", {"lm_cluster": 5}), 
          ("per-iteration", {"lm_cluster": 0, "lm_single": 0}))
 rounds = 0
 while time.time() < t_end:
