@@ -24,6 +24,7 @@ import argparse
 import ctypes
 import json
 import os
+import re
 import statistics
 import sys
 import time
@@ -412,10 +413,27 @@ def dist_free_default(args):
             and os.environ.get("NOS_BENCH_FORCE_DIST", "0") != "1")
 
 
-def valu_floor_ms(problem, dtype, n):
+def valu_floor_ms(problem, dtype, n, layout="flat"):
     """VALU-issue floor of one pass: VALU instructions per correspondence from the newest committed SQ counter pass of the
-    streaming kernel of this problem (SQ_INSTS_VALU), 4 cycles per wave instruction, 1024 SIMDs, 2.4 GHz."""
+    streaming kernel of this problem (SQ_INSTS_VALU), 4 cycles per wave instruction, 1024 SIMDs, 2.4 GHz.  The
+    voxel-indexed layout has its own kernel and its own counter pass (tools/profile_stages.sh, stage `indexed`: 10 M
+    points, fp64, one slot)."""
     import glob
+    if layout == "indexed":
+        def order(path):  # newest round first; within a round the untagged set ("r04_") is the final one
+            m = re.match(r"r(\d+)([a-z]*)_", os.path.basename(path))
+            return (int(m.group(1)), m.group(2) == "", m.group(2)) if m else (0, False, "")
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_indexed_summary.json")), key=order, reverse=True):
+            try:
+                prof = json.load(open(path))
+            except Exception:  # noqa: BLE001
+                continue
+            for name, k in (prof.get("kernels") or {}).items():
+                insts = (k.get("sq") or {}).get("SQ_INSTS_VALU")
+                if "assemble_indexed_kernel" in name and insts and dtype == "f64":
+                    ipc = insts * 64.0 / 10_000_000
+                    return ipc * n / 64.0 * 4.0 / (1024.0 * 2.4e9) * 1e3, ipc, os.path.relpath(path, ROOT)
+        return None, None, None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_*summary*.json")), reverse=True):
         try:
             prof = json.load(open(path))
@@ -704,7 +722,7 @@ def main():
             sym = ctx.last_kernel()
             b2 = d2.stream_bytes
             med = leg["ms_per_step"]["median"]
-            floor, ipc, src = valu_floor_ms(problem, dtype, points)
+            floor, ipc, src = valu_floor_ms(problem, dtype, points, layout)
             entry = {"ms_per_step": leg["ms_per_step"], "steps": k2, "trains": 3, "points": points, "dtype": dtype,
                      "bytes_per_step": b2, "frac_hbm": b2 / (med * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                      "value": points / (med * 1e-3), "unit": "corr/s",

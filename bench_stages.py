@@ -263,9 +263,17 @@ def stage_pgo(ctx, pkg, want_cpu):
     lin_call = timed_ms(ctx, g.linearize, reps=5)
     lin_ms = g.time_sweep("linearize", repeats=10)
     mv_ms = g.time_sweep("matvec", 1e-3, repeats=20)
-    # records a sweep touches once: poses 64 B, constraints 64 B, adjacency 2 x (4 + 4) B per constraint, own rows
-    lin_bytes = 64 * N + 64 * M + 16 * M + (21 * 8 + 48) * N          # + diagonal blocks and gradient written
-    mv_bytes = 64 * N + 64 * M + 16 * M + (48 + 48 + 48) * N           # + x read, y written, 6 diagonal entries read
+    # records a sweep touches once.  Linearisation (owner computes): poses 64 B, constraints 64 B, adjacency 2 x (4 + 4) B per
+    # constraint, diagonal blocks (21 doubles) and gradient (6) written.  Product (block-local): one 80-byte entry per
+    # constraint and block it touches, poses 64 B + halo poses again (pose 64 B + x 48 B), x read, y written, 6 diagonal entries
+    # read; in a PCG iteration it also forms the direction (z read, p_new written).
+    lay = g.layout_info()
+    E, halo = lay["entries"], lay["halo_poses"]
+    lin_bytes = 64 * N + 64 * M + 16 * M + (21 * 8 + 48) * N
+    if E:
+        mv_bytes = 80 * E + 64 * N + (64 + 48) * halo + (48 + 48 + 48) * N
+    else:
+        mv_bytes = 64 * N + 64 * M + 16 * M + (48 + 48 + 48) * N
     out = {}
     e = {"poses": N, "constraints": M, "ms": {"min": lin_ms, "median": lin_ms, "max": lin_ms, "n": 10},
          "ms_blocking_call": lin_call, "value": M / (lin_ms * 1e-3), "unit": "constraint linearisations/s",
@@ -283,14 +291,17 @@ def stage_pgo(ctx, pkg, want_cpu):
     t2 = timed_ms(ctx, lambda: g.solve(1e-3, k2, 0.0), reps=3, warm=0)["median"]
     it_ms = (t2 - t1) / (k2 - k1)
     setup_ms = t1 - k1 * it_ms
-    # vectors of 48 B per pose: update reads p, q, x, r and writes x, r; restriction reads r + pose; preconditioner reads
-    # 21 + 6 and writes 6, reads pose; direction reads z, p writes p; PCR reads 2 x 36 doubles per aggregate and level
-    n_agg = (N + 47) // 48
-    levels = int(np.ceil(np.log2(n_agg)))
-    it_bytes = mv_bytes + 6 * 48 * N + (48 + 64) * N + (21 * 8 + 48 + 48 + 64) * N + 3 * 48 * N + levels * 2 * 36 * 8 * n_agg
+    # the 6 launches of an iteration (vectors are 48 B per pose): product + direction (mv_bytes + z read + p_new written);
+    # update + restriction (p, q, x, r read, x, r written, pose read); 3 PCR spans (2 x 36 doubles per aggregate and level, rhs
+    # in and out per span); preconditioner + prolongation (21 factors + r + pose read, z written, coarse solution read)
+    lay = g.layout_info()
+    n_agg, levels = lay["aggregates"], lay["pcr_levels"]
+    it_bytes = (mv_bytes + 2 * 48 * N) + (6 * 48 + 64) * N + (levels * 2 * 36 * 8 + 3 * 2 * 48) * n_agg + (21 * 8 + 48 + 48 + 64) * N
     e = {"poses": N, "constraints": M, "ms": {"min": it_ms, "median": it_ms, "max": it_ms, "n": k2 - k1},
-         "launches_per_iteration": 6, "setup_ms_per_solve": setup_ms,
-         "setup": "block-Jacobi factorisation + the coarse operator (18 probing products) + PCR elimination, once per solve",
+         "launches_per_iteration": 6 if E else 7,
+         "launches": "product (+ direction, + p.Ap tail) | update + restriction | 3 PCR spans | preconditioner + prolongation (+ r.z tail)",
+         "layout": lay, "setup_ms_per_solve": setup_ms,
+         "setup": "block-Jacobi factorisation + the coarse operator (3 assembly sweeps) + PCR elimination, once per solve",
          "value": 1e3 / it_ms, "unit": "PCG iterations/s",
          "timing": "(wall of a %d-iteration solve − wall of a %d-iteration solve) / %d, tolerance 0, median of 3 each" % (k2, k1, k2 - k1)}
     out["pgo_pcg_iteration"] = roof(e, it_bytes, it_ms)

@@ -428,6 +428,11 @@ int nos_pgo_get_state(nos_pose_graph* pg, double* poses, double* switches);
 int nos_pgo_get_vector(nos_pose_graph* pg, int which, double* out);
 /* y = (J^T J with its diagonal scaled by 1 + lambda) x for host vectors.  Diagnostics. */
 int nos_pgo_matvec(nos_pose_graph* pg, double lambda, const double* x, double* y);
+/* What the sweeps have to touch (bench.py's byte models): info[0] poses, [1] constraints, [2] entries of the block-local
+ * product (one per constraint and block it touches; 0 = the owner-computes product is in use), [3] poses per block,
+ * [4] blocks, [5] halo poses over all blocks, [6] aggregates of the coarse level, [7] PCR levels (6, 7: 0 before the
+ * first two-level solve). */
+int nos_pgo_layout_info(const nos_pose_graph* pg, unsigned long long info[8]);
 /* Timing aid (bench.py): `repeats` device-resident products of the kind a PCG iteration makes (x = the gradient of the
  * last nos_pgo_linearize), back to back on the context's stream between one pair of HIP events → milliseconds per
  * product.  which: 0 the product of a PCG iteration (with its in-launch p.Ap sum), 1 the linearisation sweeps. */

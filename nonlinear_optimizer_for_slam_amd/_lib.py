@@ -33,7 +33,7 @@ C_ABI_SYMBOLS = (
     "nos_scan_destroy", "nos_scan_size", "nos_scan_sort_by_cell", "nos_scan_order", "nos_ndt_match", "nos_ndt_indexed_dataset_create", "nos_ndt_match_indexed", "nos_ndt_map_build", "nos_map_stats_size",
     "nos_map_stats_get", "nos_map_stats_get_eigen", "nos_map_stats_destroy", "nos_dataset_drop_last_matches", "nos_pgo_create", "nos_pgo_destroy", "nos_pgo_num_unknowns",
     "nos_pgo_linearize", "nos_pgo_solve", "nos_pgo_retract", "nos_pgo_get_state", "nos_pgo_get_vector",
-    "nos_pgo_matvec", "nos_pgo_time_sweep", "nos_debug_lm_step", "nos_dataset_destroy", "nos_dataset_size", "nos_dataset_dtype", "nos_dataset_stream_bytes",
+    "nos_pgo_matvec", "nos_pgo_time_sweep", "nos_pgo_layout_info", "nos_debug_lm_step", "nos_dataset_destroy", "nos_dataset_size", "nos_dataset_dtype", "nos_dataset_stream_bytes",
     "nos_dataset_set_simd_class",
     "nos_ndt6_accumulate", "nos_ndt3_accumulate", "nos_reproj_accumulate",
     "nos_ndt6_accumulate_async", "nos_ndt3_accumulate_async", "nos_reproj_accumulate_async",
@@ -155,6 +155,8 @@ def _declare(lib):
     lib.nos_pgo_get_state.argtypes = [vp, dp, dp]
     lib.nos_pgo_get_vector.argtypes = [vp, i, dp]
     lib.nos_pgo_matvec.argtypes = [vp, ctypes.c_double, dp, dp]
+    if hasattr(lib, "nos_pgo_layout_info"):
+        lib.nos_pgo_layout_info.argtypes = [vp, ctypes.POINTER(ctypes.c_ulonglong)]
     if hasattr(lib, "nos_debug_lm_step"):
         lib.nos_debug_lm_step.argtypes = [vp, i, dp, dp, dp]
     if hasattr(lib, "nos_pgo_time_sweep"):  # absent from older builds loaded through NOS_HIP_LIB

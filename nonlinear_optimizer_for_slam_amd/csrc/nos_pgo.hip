@@ -34,6 +34,7 @@ struct nos_pose_graph {
   uint32_t* d_bhalo = nullptr;     // halo pose ids, block after block
   uint32_t* d_bhalo_off = nullptr; // [n_blocks + 1]
   uint32_t block_poses = 0, n_blocks = 0, n_entries = 0;
+  size_t n_halo = 0;               // halo poses over all blocks
   int product_grid = 0;            // workgroups of the block-local product (what is resident), decided at the first launch
   nos::PgoBlockView bview{};
   // coarse level of the two-level preconditioner (pgo_coarse_kernels.hpp), allocated on first use
@@ -86,7 +87,7 @@ int pgo_launch_product(nos_pose_graph* pg, double lambda, const double* x, doubl
   if (pg->block_poses != 0) {
     constexpr int kP = 128, kT = 256;
     const size_t lds = ((size_t(kP) + pg->bview.halo_cap) * 14 + size_t(pg->bview.slot_cap) * 6) * sizeof(double);
-    auto* kernel = nos::pgo_matvec_block_kernel<kP, kT>;
+    auto* kernel = switch_rows ? nos::pgo_matvec_block_kernel<kP, kT, true> : nos::pgo_matvec_block_kernel<kP, kT, false>;
     if (lds > size_t(48) * 1024) {
       const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
       if (ea != hipSuccess) return fail(NOS_ERR_HIP, "pose-graph product: %zu bytes of LDS refused: %s", lds, hipGetErrorString(ea));
@@ -98,7 +99,7 @@ int pgo_launch_product(nos_pose_graph* pg, double lambda, const double* x, doubl
       pg->product_grid = int(std::min<size_t>(pg->n_blocks, size_t(per_cu) * size_t(slot.num_cus)));
     }
     hipLaunchKernelGGL(kernel, dim3(unsigned(pg->product_grid)), dim3(kT), lds, slot.stream, pg->view, pg->bview, pg->d_hdiag,
-                       pg->d_hs, lambda, x, y, switch_rows, tail, z, x_new);
+                       pg->d_hs, lambda, x, y, tail, z, x_new);
   } else {
     const uint32_t pose_blocks = (pg->n_poses + 255) / 256;
     const uint32_t mv_blocks = pose_blocks + (switch_rows ? (pg->n_edges + 255) / 256 : 0u);
@@ -333,8 +334,13 @@ int nos_pgo_create(nos_ctx* ctx, size_t n_poses, const double* poses, size_t n_e
   constexpr uint32_t kBlockPoses = 128, kSlotLimit = 2304, kHaloLimit = 512;  // LDS: (128 + 512) x 112 B + 2304 x 48 B = 182 KB
                                                                                // is the refusal line; a trajectory graph needs ≈ 70 KB
   const uint32_t n_blocks = (N + kBlockPoses - 1) / kBlockPoses;
-  std::vector<uint32_t> bent_off(size_t(n_blocks) + 1, 0), bent_edge, bhalo, bhalo_off(size_t(n_blocks) + 1, 0);
-  std::vector<double> bent;
+  std::vector<uint32_t> bent_off(size_t(n_blocks) + 1, 0), bhalo_off(size_t(n_blocks) + 1, 0);
+  struct Piece {  // what one host thread produced for its contiguous range of blocks [first_block, …)
+    uint32_t first_block = 0;
+    std::vector<double> ent;  // [entries][10]
+    std::vector<uint32_t> edge, halo;
+  };
+  std::vector<Piece> pieces;
   uint32_t slot_cap = 0, halo_cap = 0;
   bool blocks_ok = ctx->settings.pgo_block != 0 && M > 0;
   if (blocks_ok) {
@@ -345,21 +351,26 @@ int nos_pgo_create(nos_ctx* ctx, size_t n_poses, const double* poses, size_t n_e
     blocks_ok = slot_cap <= kSlotLimit;
   }
   if (blocks_ok) {
-    // two passes over the blocks, both spread over a few host threads (blocks are independent): sizes, then contents
+    // ONE pass over the blocks, spread over a few host threads (blocks are independent; a thread takes a contiguous range of
+    // blocks, so what it produces is a contiguous piece of every list), then the pieces are laid end to end
     struct Ent {
       uint32_t e, slot_r, slot_q;
     };
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
     const unsigned n_threads = std::min<unsigned>(std::min(16u, hw), std::max(1u, n_blocks / 64u));
-    auto for_blocks = [&](auto&& body) {
+    const uint32_t per = (n_blocks + n_threads - 1) / n_threads;
+    pieces.resize(n_threads);
+    std::atomic<bool> too_large{false};
+    {
       std::vector<std::thread> pool;
       for (unsigned w = 0; w < n_threads; ++w)
         pool.emplace_back([&, w]() {
-          const uint32_t per = (n_blocks + n_threads - 1) / n_threads;
           const uint32_t b0 = std::min(n_blocks, w * per), b1 = std::min(n_blocks, b0 + per);
+          Piece& out = pieces[w];
+          out.first_block = b0;
           std::vector<Ent> ents;
           std::vector<uint32_t> halo;
-          for (uint32_t b = b0; b < b1; ++b) {
+          for (uint32_t b = b0; b < b1 && !too_large.load(std::memory_order_relaxed); ++b) {
             const uint32_t lo = b * kBlockPoses, hi = std::min(N, lo + kBlockPoses), a0 = adj_off[lo];
             ents.clear();
             halo.clear();
@@ -383,17 +394,31 @@ int nos_pgo_create(nos_ctx* ctx, size_t n_poses, const double* poses, size_t n_e
             ents.resize(n_out);
             std::sort(halo.begin(), halo.end());
             halo.erase(std::unique(halo.begin(), halo.end()), halo.end());
-            body(b, lo, hi, ents, halo);
+            bent_off[b + 1] = uint32_t(ents.size());
+            bhalo_off[b + 1] = uint32_t(halo.size());
+            if (halo.size() > kHaloLimit) too_large.store(true);
+            auto local = [&](uint32_t pose) -> uint32_t {
+              if (pose >= lo && pose < hi) return pose - lo;
+              return kBlockPoses + uint32_t(std::lower_bound(halo.begin(), halo.end(), pose) - halo.begin());
+            };
+            size_t k = out.edge.size();
+            out.ent.resize(size_t(10) * (k + ents.size()));
+            out.edge.resize(k + ents.size());
+            for (const Ent& en : ents) {
+              double* rec = out.ent.data() + size_t(10) * k;
+              for (int q = 0; q < 8; ++q) rec[q] = edge_rec[size_t(8) * en.e + q];
+              const unsigned long long w8 = (unsigned long long)en.e | ((unsigned long long)local(uint32_t(ref[en.e])) << 32) |
+                                            ((unsigned long long)local(uint32_t(qry[en.e])) << 48);
+              const unsigned long long w9 = (unsigned long long)en.slot_r | ((unsigned long long)en.slot_q << 16);
+              memcpy(&rec[8], &w8, sizeof w8);
+              memcpy(&rec[9], &w9, sizeof w9);
+              out.edge[k++] = en.e;
+            }
+            out.halo.insert(out.halo.end(), halo.begin(), halo.end());
           }
         });
       for (std::thread& th : pool) th.join();
-    };
-    std::atomic<bool> too_large{false};
-    for_blocks([&](uint32_t b, uint32_t, uint32_t, const std::vector<Ent>& ents, const std::vector<uint32_t>& halo) {
-      bent_off[b + 1] = uint32_t(ents.size());
-      bhalo_off[b + 1] = uint32_t(halo.size());
-      if (halo.size() > kHaloLimit) too_large.store(true);
-    });
+    }
     blocks_ok = !too_large.load();
     if (blocks_ok) {
       for (uint32_t b = 0; b < n_blocks; ++b) {
@@ -401,27 +426,6 @@ int nos_pgo_create(nos_ctx* ctx, size_t n_poses, const double* poses, size_t n_e
         bent_off[b + 1] += bent_off[b];
         bhalo_off[b + 1] += bhalo_off[b];
       }
-      bent.resize(size_t(10) * bent_off[n_blocks]);
-      bent_edge.resize(bent_off[n_blocks]);
-      bhalo.resize(bhalo_off[n_blocks]);
-      for_blocks([&](uint32_t b, uint32_t lo, uint32_t hi, const std::vector<Ent>& ents, const std::vector<uint32_t>& halo) {
-        auto local = [&](uint32_t pose) -> uint32_t {
-          if (pose >= lo && pose < hi) return pose - lo;
-          return kBlockPoses + uint32_t(std::lower_bound(halo.begin(), halo.end(), pose) - halo.begin());
-        };
-        size_t k = bent_off[b];
-        for (const Ent& en : ents) {
-          double* rec = bent.data() + size_t(10) * k;
-          for (int q = 0; q < 8; ++q) rec[q] = edge_rec[size_t(8) * en.e + q];
-          const unsigned long long w8 = (unsigned long long)en.e | ((unsigned long long)local(uint32_t(ref[en.e])) << 32) |
-                                        ((unsigned long long)local(uint32_t(qry[en.e])) << 48);
-          const unsigned long long w9 = (unsigned long long)en.slot_r | ((unsigned long long)en.slot_q << 16);
-          memcpy(&rec[8], &w8, sizeof w8);
-          memcpy(&rec[9], &w9, sizeof w9);
-          bent_edge[k++] = en.e;
-        }
-        std::copy(halo.begin(), halo.end(), bhalo.begin() + bhalo_off[b]);
-      });
     }
   }
   nos_pose_graph* pg = new (std::nothrow) nos_pose_graph();
@@ -441,14 +445,30 @@ int nos_pgo_create(nos_ctx* ctx, size_t n_poses, const double* poses, size_t n_e
   if (e == hipSuccess) e = upload(&pg->d_adj_off, adj_off);
   if (e == hipSuccess) e = upload(&pg->d_adj, adj);
   if (blocks_ok) {
-    if (e == hipSuccess) e = upload(&pg->d_bent, bent);
+    // the pieces go to the device end to end (no host-side concatenation); one spare element behind the entry and halo
+    // lists: the product kernel's unconditional (clamped) loads of a block without entries or without a halo then stay
+    // inside the allocation
+    const size_t n_ent_total = bent_off[n_blocks], n_halo_total = bhalo_off[n_blocks];
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&pg->d_bent), (n_ent_total + 1) * 10 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&pg->d_bent_edge), std::max<size_t>(n_ent_total, 1) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&pg->d_bhalo), (n_halo_total + 1) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(pg->d_bent + n_ent_total * 10, 0, 10 * sizeof(double));
+    if (e == hipSuccess) e = hipMemset(pg->d_bhalo + n_halo_total, 0, sizeof(uint32_t));
+    for (const Piece& pc : pieces) {
+      const size_t eo = bent_off[pc.first_block], ho = bhalo_off[pc.first_block];
+      if (e == hipSuccess && !pc.edge.empty()) {
+        e = hipMemcpy(pg->d_bent + eo * 10, pc.ent.data(), pc.ent.size() * sizeof(double), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(pg->d_bent_edge + eo, pc.edge.data(), pc.edge.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+      }
+      if (e == hipSuccess && !pc.halo.empty())
+        e = hipMemcpy(pg->d_bhalo + ho, pc.halo.data(), pc.halo.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess) e = upload(&pg->d_bent_off, bent_off);
-    if (e == hipSuccess) e = upload(&pg->d_bent_edge, bent_edge);
-    if (e == hipSuccess) e = upload(&pg->d_bhalo, bhalo);
     if (e == hipSuccess) e = upload(&pg->d_bhalo_off, bhalo_off);
     pg->block_poses = kBlockPoses;
     pg->n_blocks = n_blocks;
-    pg->n_entries = uint32_t(bent_edge.size());
+    pg->n_entries = uint32_t(n_ent_total);
+    pg->n_halo = n_halo_total;
   }
   {
     std::vector<int32_t> r(ref, ref + M), q(qry, qry + M);
@@ -730,6 +750,14 @@ int nos_pgo_get_vector(nos_pose_graph* pg, int which, double* out) {
   for (size_t i = 0; i < N; ++i)
     for (int k = 0; k < 6; ++k) out[size_t(k) * N + i] = rec[6 * i + k];
   for (size_t e = 0; e < pg->n_edges; ++e) out[6 * N + e] = rec[6 * N + e];
+  return NOS_OK;
+}
+
+int nos_pgo_layout_info(const nos_pose_graph* pg, unsigned long long info[8]) {
+  if (!pg || !info) return fail(NOS_ERR_INVALID_ARGUMENT, "NULL argument");
+  const bool block = pg->block_poses != 0;
+  info[0] = pg->n_poses, info[1] = pg->n_edges, info[2] = block ? pg->n_entries : 0, info[3] = block ? pg->block_poses : 0;
+  info[4] = block ? pg->n_blocks : 0, info[5] = block ? pg->n_halo : 0, info[6] = pg->n_agg, info[7] = pg->pcr_levels;
   return NOS_OK;
 }
 

@@ -574,13 +574,16 @@ constexpr uint32_t kPgoNoSlot = 0xFFFFu;
 //             range now, so that their latency is gone by phase B;
 //   phase A   (above) every operand from LDS or from the entry stream: no dependent global gather left in the loop;
 //   phase B   one lane per pose.
-template <int P, int T>
+// SW: some switch is free (the vectors carry switch rows).  Its own instantiation because the switch rows gather their
+// operands by constraint id inside phase A, and a load behind a branch there costs the counted waits of the ping-pong —
+// in every instantiation that contains it, taken or not (read in the ISA).
+template <int P, int T, bool SW>
 __global__ __launch_bounds__(T) void pgo_matvec_block_kernel(PgoView G, PgoBlockView B, const double* __restrict__ hdiag,
                                                              const double* __restrict__ h_s, double lambda,
                                                              const double* __restrict__ x, double* __restrict__ y,
-                                                             int switch_rows, PgoTail tail,
-                                                             const double* __restrict__ z = nullptr,
+                                                             PgoTail tail, const double* __restrict__ z = nullptr,
                                                              double* __restrict__ x_new = nullptr) {
+  constexpr bool switch_rows = SW;
   // z != nullptr: the PCG's direction update rides in the staging — the vector multiplied is x_new = z + beta x (beta =
   // scalars[6] of the preconditioner sweep's tail; x untouched after a breakdown, scalars[7]), formed where x is read and
   // written to x_new by the block that owns the row: the separate p = z + beta p pass (144 MB at 1 M poses) is gone.
@@ -599,38 +602,67 @@ __global__ __launch_bounds__(T) void pgo_matvec_block_kernel(PgoView G, PgoBlock
   const size_t N6 = size_t(6) * G.n_poses;
   double* ys = y + N6;
   using V2 = double __attribute__((ext_vector_type(2)));
+  static_assert((P * 4) % T == 0, "the block's pose records are staged as whole rounds of 16-byte pieces");
+  constexpr int kPoseRounds = P * 4 / T, kVecRounds = (P * 3 + T - 1) / T;
+  V2* pose_s2 = reinterpret_cast<V2*>(pose_s);
+  V2* x_s2 = reinterpret_cast<V2*>(x_s);
+  const V2* pose2 = reinterpret_cast<const V2*>(G.pose);
+  const V2* x2 = reinterpret_cast<const V2*>(x);
+  const V2* z2 = reinterpret_cast<const V2*>(fused ? z : x);
+  V2* xn2 = reinterpret_cast<V2*>(x_new);
+  auto direction2 = [&](V2 xv, V2 zv) -> V2 { return (!fused || frozen) ? xv : V2{zv[0] + beta * xv[0], zv[1] + beta * xv[1]}; };
   double xy = 0.0;
+  // what a block's staging needs before it can ask for anything else: read one block ahead
+  struct Meta { uint32_t h0, n_halo, e0, n_ent, a0; };
+  auto load_meta = [&](uint32_t b) -> Meta {
+    const uint32_t h0 = B.halo_off[b], e0 = B.entry_off[b];
+    return Meta{h0, B.halo_off[b + 1] - h0, e0, B.entry_off[b + 1] - e0, G.adj_off[b * P]};
+  };
+  Meta next = load_meta(blockIdx.x < B.n_blocks ? blockIdx.x : 0u);
   for (uint32_t blk = blockIdx.x; blk < B.n_blocks; blk += gridDim.x) {
+    const Meta M = next;
+    next = load_meta(blk + gridDim.x < B.n_blocks ? blk + gridDim.x : blk);
     const uint32_t base = blk * P;
     const uint32_t n_in = G.n_poses - base < uint32_t(P) ? G.n_poses - base : uint32_t(P);
-    const uint32_t h0 = B.halo_off[blk], n_halo = B.halo_off[blk + 1] - h0;
-    for (uint32_t t = threadIdx.x; t < n_in * 8; t += T) pose_s[t] = G.pose[size_t(8) * base + t];
-    for (uint32_t t = threadIdx.x; t < n_in * 6; t += T) {
-      const double v = direction(size_t(6) * base + t);
-      x_s[t] = v;
-      if (fused) x_new[size_t(6) * base + t] = v;
-    }
-    for (uint32_t t = threadIdx.x; t < n_halo * 8; t += T)
-      pose_s[size_t(P) * 8 + t] = G.pose[size_t(8) * B.halo[h0 + (t >> 3)] + (t & 7u)];
-    for (uint32_t t = threadIdx.x; t < n_halo * 6; t += T)
-      x_s[size_t(P) * 6 + t] = direction(size_t(6) * B.halo[h0 + t / 6u] + t % 6u);
-    // phase B's own-row operands, requested now
-    double hd[6] = {0, 0, 0, 0, 0, 0};
-    uint32_t a_lo = 0, a_hi = 0;
-    const uint32_t a0 = G.adj_off[base];
-    if (threadIdx.x < n_in) {
-      const uint32_t i = base + threadIdx.x;
-      const int dg[6] = {0, 6, 11, 15, 18, 20};
+    const uint32_t h0 = M.h0, n_halo = M.n_halo, e0 = M.e0, n_ent = M.n_ent, a0 = M.a0;
+    // Staging.  EVERY load of the block's start is issued before the first wait (a loop of "load, store to LDS" pays one
+    // memory round trip per turn — measured: 16 µs per block, 250 µs per product; profiles/r04c_pgo_summary.json): indices
+    // past the end are clamped and their values dropped, so no load sits behind a branch.  Order = the order the results
+    // are needed in: halo ids (the halo loads depend on them), own poses and vector entries, halo pieces, the first
+    // entry of phase A, phase B's own-row operands.
+    //   halo pieces: 7 per halo pose (4 of its record, 3 of its vector entries), two per lane and round
+    const uint32_t n_pieces = n_halo * 7u;
+    uint32_t hj[2], hid[2];
 #pragma unroll
-      for (int m = 0; m < 6; ++m) hd[m] = hdiag[size_t(dg[m]) * G.n_poses + i];
-      a_lo = G.adj_off[i] - a0;
-      a_hi = G.adj_off[i + 1] - a0;
+    for (int u = 0; u < 2; ++u) {
+      const uint32_t j = threadIdx.x + u * T;
+      hj[u] = j < n_pieces ? j : (n_pieces ? n_pieces - 1 : 0u);
+      hid[u] = B.halo[h0 + hj[u] / 7u];  // the list ends with one spare id: valid for an empty halo as well
     }
-    __syncthreads();
-
-    const uint32_t e0 = B.entry_off[blk], n_ent = B.entry_off[blk + 1] - e0;
+    V2 pv[kPoseRounds], xv[kVecRounds], zv[kVecRounds];
+#pragma unroll
+    for (int m = 0; m < kPoseRounds; ++m) {
+      const uint32_t idx = threadIdx.x + m * T;
+      pv[m] = pose2[size_t(4) * base + (idx < n_in * 4 ? idx : n_in * 4 - 1)];
+    }
+#pragma unroll
+    for (int m = 0; m < kVecRounds; ++m) {
+      const uint32_t idx = threadIdx.x + m * T;
+      const size_t src = size_t(3) * base + (idx < n_in * 3 ? idx : n_in * 3 - 1);
+      xv[m] = x2[src];
+      zv[m] = z2[src];
+    }
+    V2 hv[2], hz[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const uint32_t c = hj[u] % 7u;
+      const size_t vec = size_t(3) * hid[u] + (c < 4 ? 0u : c - 4u);
+      const V2* src = c < 4 ? pose2 + size_t(4) * hid[u] + c : x2 + vec;  // one load through a selected address
+      hv[u] = *src;
+      hz[u] = z2[vec];
+    }
     auto load_entry = [&](uint32_t k, double (&rec)[10]) {  // unconditional: an index past the end re-reads the last entry
-      const uint32_t kk = k < n_ent ? k : n_ent - 1;
+      const uint32_t kk = k < n_ent ? k : (n_ent ? n_ent - 1 : 0u);  // (the array ends with one spare record)
       const V2* q = reinterpret_cast<const V2*>(B.entries + size_t(10) * (e0 + kk));
 #pragma unroll
       for (int m = 0; m < 5; ++m) {
@@ -639,10 +671,61 @@ __global__ __launch_bounds__(T) void pgo_matvec_block_kernel(PgoView G, PgoBlock
         rec[2 * m + 1] = v[1];
       }
     };
+    double recA[10], recB[10];
+    load_entry(threadIdx.x, recA);
+    double hd[6];
+    uint32_t a_lo, a_hi;
+    {
+      const uint32_t i = base + (threadIdx.x < n_in ? threadIdx.x : n_in - 1);
+      const int dg[6] = {0, 6, 11, 15, 18, 20};
+#pragma unroll
+      for (int m = 0; m < 6; ++m) hd[m] = hdiag[size_t(dg[m]) * G.n_poses + i];
+      a_lo = G.adj_off[i] - a0;
+      a_hi = G.adj_off[i + 1] - a0;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < kPoseRounds; ++m) {
+      const uint32_t idx = threadIdx.x + m * T;
+      if (idx < n_in * 4) pose_s2[idx] = pv[m];
+    }
+#pragma unroll
+    for (int m = 0; m < kVecRounds; ++m) {
+      const uint32_t idx = threadIdx.x + m * T;
+      if (idx < n_in * 3) {
+        const V2 v = direction2(xv[m], zv[m]);
+        x_s2[idx] = v;
+        if (fused) xn2[size_t(3) * base + idx] = v;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const uint32_t j = threadIdx.x + u * T, h = hj[u] / 7u, c = hj[u] % 7u;
+      if (j < n_pieces) {
+        if (c < 4)
+          pose_s2[size_t(P + h) * 4 + c] = hv[u];
+        else
+          x_s2[size_t(P + h) * 3 + (c - 4)] = direction2(hv[u], hz[u]);
+      }
+    }
+    for (uint32_t j = threadIdx.x + 2 * T; j < n_pieces; j += T) {  // halos beyond 2 T / 7 poses: round after round
+      const uint32_t h = j / 7u, c = j % 7u, id = B.halo[h0 + h];
+      if (c < 4)
+        pose_s2[size_t(P + h) * 4 + c] = pose2[size_t(4) * id + c];
+      else
+        x_s2[size_t(P + h) * 3 + (c - 4)] = direction2(x2[size_t(3) * id + (c - 4)], z2[size_t(3) * id + (c - 4)]);
+    }
+    __syncthreads();
+
     auto evaluate = [&](const double (&rec)[10]) {
       const unsigned long long w8 = (unsigned long long)__double_as_longlong(rec[8]), w9 = (unsigned long long)__double_as_longlong(rec[9]);
       const uint32_t e = uint32_t(w8), lr = uint32_t(w8 >> 32) & 0xFFFFu, lq = uint32_t(w8 >> 48) & 0xFFFFu;
       const uint32_t slot_r = uint32_t(w9) & 0xFFFFu, slot_q = uint32_t(w9 >> 16) & 0xFFFFu;
+      // The upper half of w9 carries nothing and, without switch rows, nobody reads e — and a loaded register nobody reads
+      // is free for the allocator the moment the load is ISSUED: it was handed out as an address register while the record
+      // was still in flight, and the write-after-write hazard turned the counted wait of the ping-pong into
+      // s_waitcnt vmcnt(0) (read in the ISA).  Reading both here keeps them occupied until the record is consumed.
+      asm volatile("" ::"v"(uint32_t(w9 >> 32)), "v"(e));
       double pr[8], pq[8], ed[8], xr[6], xq[6];
 #pragma unroll
       for (int m = 0; m < 8; ++m) {
@@ -661,8 +744,12 @@ __global__ __launch_bounds__(T) void pgo_matvec_block_kernel(PgoView G, PgoBlock
       double vr[6], vq[6], v[6];
       apply_J(Tm, 0, xr, vr);
       apply_J(Tm, 1, xq, vq);
-      const bool free_sw = switch_rows && G.sw_free[e] != 0;
-      const double xs_e = switch_rows ? direction(N6 + e) : 0.0;  // this constraint's switch component of the vector
+      bool free_sw = false;
+      double xs_e = 0.0;  // this constraint's switch component of the vector
+      if constexpr (switch_rows) {
+        free_sw = G.sw_free[e] != 0;
+        xs_e = direction(N6 + e);
+      }
       const double xse = free_sw ? xs_e : 0.0;
 #pragma unroll
       for (int m = 0; m < 6; ++m) v[m] = s * (vr[m] + vq[m]) + Tm.r[m] * xse;
@@ -671,7 +758,7 @@ __global__ __launch_bounds__(T) void pgo_matvec_block_kernel(PgoView G, PgoBlock
         add_JT(Tm, 0, v, s, c);
 #pragma unroll
         for (int m = 0; m < 6; ++m) contrib[6 * slot_r + m] = c[m];
-        if (switch_rows) {  // the switch row of this constraint, by the block that owns its reference end
+        if constexpr (switch_rows) {  // the switch row of this constraint, by the block that owns its reference end
           double out;
           if (free_sw) {
             double acc = 0.0;
@@ -693,21 +780,17 @@ __global__ __launch_bounds__(T) void pgo_matvec_block_kernel(PgoView G, PgoBlock
         for (int m = 0; m < 6; ++m) contrib[6 * slot_q + m] = c[m];
       }
     };
-    // phase A: two named record buffers, the next entry's 80 bytes in flight while the current one is evaluated
-    if (n_ent > 0) {
-      double recA[10], recB[10];
-      uint32_t k = threadIdx.x;
-      load_entry(k, recA);
-      for (; k < n_ent; k += 2 * T) {
-        load_entry(k + T, recB);
-        __builtin_amdgcn_sched_barrier(0);
-        evaluate(recA);
-        __builtin_amdgcn_sched_barrier(0);
-        load_entry(k + 2 * T, recA);
-        __builtin_amdgcn_sched_barrier(0);
-        if (k + T < n_ent) evaluate(recB);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+    // phase A: two named record buffers, the next entry's 80 bytes in flight while the current one is evaluated (the first
+    // entry was requested with the staging)
+    for (uint32_t k = threadIdx.x; k < n_ent; k += 2 * T) {
+      load_entry(k + T, recB);
+      __builtin_amdgcn_sched_barrier(0);
+      evaluate(recA);
+      __builtin_amdgcn_sched_barrier(0);
+      load_entry(k + 2 * T, recA);
+      __builtin_amdgcn_sched_barrier(0);
+      if (k + T < n_ent) evaluate(recB);
+      __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
     // phase B: one lane per pose, its slots in adjacency order

@@ -74,6 +74,14 @@ class PoseGraph:
         check(self._lib.nos_pgo_matvec(self._h, ctypes.c_double(lam), _dp(x), _dp(y)), "nos_pgo_matvec")
         return y
 
+    def layout_info(self):
+        """What the sweeps touch (nos_pgo_layout_info): poses, constraints, entries / block size / blocks / halo poses of
+        the block-local product (0 when the owner-computes product runs), aggregates and PCR levels of the coarse level."""
+        info = (ctypes.c_ulonglong * 8)()
+        check(self._lib.nos_pgo_layout_info(self._h, info), "nos_pgo_layout_info")
+        keys = ("poses", "constraints", "entries", "block_poses", "blocks", "halo_poses", "aggregates", "pcr_levels")
+        return dict(zip(keys, (int(v) for v in info)))
+
     def time_sweep(self, which, lam=1e-3, repeats=20):
         """ms per device-resident sweep (nos_pgo_time_sweep): which = "matvec" (the product of a PCG iteration) or
         "linearize" (the linearisation kernels, without the host's scalar readbacks)."""
