@@ -91,6 +91,12 @@ struct TwoNearest {
   }
 };
 
+// Squared distance, one fixed evaluation order for every form of the search (left to the compiler, "ex ex + ey ey + ez ez"
+// fuses a different product in different surroundings: an ulp apart, enough to move a point across the radius test).
+__device__ __forceinline__ double match_dist(double ex, double ey, double ez) {
+  return __builtin_fma(ez, ez, __builtin_fma(ey, ey, ex * ex));
+}
+
 // The (up to) two nearest valid voxel means within the radius of the world point q — FLANN radiusSearch with
 // max_neighbors = 2 on squared distances, ties broken by original voxel id.  Same result from both grid forms.
 __device__ __forceinline__ void find_two_nearest(const MapView& map, double qx, double qy, double qz, TwoNearest& best) {
@@ -119,8 +125,7 @@ __device__ __forceinline__ void find_two_nearest(const MapView& map, double qx, 
         for (uint32_t j = b; j < e; ++j) {
           const V2 m01 = rec[2 * size_t(j)];
           const V2 m23 = rec[2 * size_t(j) + 1];
-          const double ex = qx - m01[0], ey = qy - m01[1], ez = qz - m23[0];
-          const double dist = ex * ex + ey * ey + ez * ez;
+          const double dist = match_dist(qx - m01[0], qy - m01[1], qz - m23[0]);
           if (dist < map.radius_sq) best.offer(dist, j, uint32_t(__double_as_longlong(m23[1])));
         }
       }
@@ -147,7 +152,7 @@ __device__ __forceinline__ void find_two_nearest(const MapView& map, double qx, 
           const double ex = qx - map.mean[3 * size_t(j)];
           const double ey = qy - map.mean[3 * size_t(j) + 1];
           const double ez = qz - map.mean[3 * size_t(j) + 2];
-          const double dist = ex * ex + ey * ey + ez * ez;
+          const double dist = match_dist(ex, ey, ez);
           if (dist < map.radius_sq) best.offer(dist, j, map.orig_id[j]);
         }
       }
