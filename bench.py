@@ -413,6 +413,12 @@ def dist_free_default(args):
             and os.environ.get("NOS_BENCH_FORCE_DIST", "0") != "1")
 
 
+def profile_order(path):
+    """Sort key for committed profile summaries: newest round first; within a round the untagged set ("r04_") is the final one."""
+    m = re.match(r"r(\d+)([a-z]*)_", os.path.basename(path))
+    return (int(m.group(1)), m.group(2) == "", m.group(2)) if m else (0, False, "")
+
+
 def valu_floor_ms(problem, dtype, n, layout="flat"):
     """VALU-issue floor of one pass: VALU instructions per correspondence from the newest committed SQ counter pass of the
     streaming kernel of this problem (SQ_INSTS_VALU), 4 cycles per wave instruction, 1024 SIMDs, 2.4 GHz.  The
@@ -420,10 +426,7 @@ def valu_floor_ms(problem, dtype, n, layout="flat"):
     points, fp64, one slot)."""
     import glob
     if layout == "indexed":
-        def order(path):  # newest round first; within a round the untagged set ("r04_") is the final one
-            m = re.match(r"r(\d+)([a-z]*)_", os.path.basename(path))
-            return (int(m.group(1)), m.group(2) == "", m.group(2)) if m else (0, False, "")
-        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_indexed_summary.json")), key=order, reverse=True):
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_indexed_summary.json")), key=profile_order, reverse=True):
             try:
                 prof = json.load(open(path))
             except Exception:  # noqa: BLE001
@@ -434,7 +437,7 @@ def valu_floor_ms(problem, dtype, n, layout="flat"):
                     ipc = insts * 64.0 / 10_000_000
                     return ipc * n / 64.0 * 4.0 / (1024.0 * 2.4e9) * 1e3, ipc, os.path.relpath(path, ROOT)
         return None, None, None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_*summary*.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_*summary*.json")), key=profile_order, reverse=True):
         try:
             prof = json.load(open(path))
         except Exception:  # noqa: BLE001
@@ -858,7 +861,7 @@ def main():
     try:
         import glob
         one_launch = device_loop and getattr(work, "launches_of_last_solve", 0) == 1
-        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench*summary*.json")), reverse=True):
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench*summary*.json")), key=profile_order, reverse=True):
             prof = json.load(open(path))
             if (prof.get("points_per_gpu") == n_local and prof.get("dtype") == args.dtype and args.layout == "flat"
                     and prof.get("problem", "ndt6") == args.problem
@@ -877,7 +880,7 @@ def main():
     # is not the figure of merit (the resident reprojection solve: data on chip, no loads at all).
     try:
         import glob
-        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_*summary*.json")), reverse=True):
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_*summary*.json")), key=profile_order, reverse=True):
             prof = json.load(open(path))
             ipc = (prof.get("sq_derived") or {}).get("valu_instructions_per_correspondence")
             if (ipc and prof.get("dtype") == args.dtype and prof.get("problem", "ndt6") == args.problem
