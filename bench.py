@@ -706,6 +706,7 @@ def main():
     # ---- the other single-GPU configurations, short trains with the same bracket timing (driver-timed lines instead of
     # builder-run ones): configs[2], the configs[0] shape on the GPU, the fp32 classes' storage, the planar solver
     other_configs = None
+    cpu_leg_seconds = 0.0  # wall time of the CPU legs of other_configs (solver configurations here, stages in bench_stages)
     if dist is None and other_wanted and planes is not None:
         other_configs = {}
         specs = [("reproj_f64_2M (BASELINE.json configs[2])", "reproj", "f64", 2_000_000, "flat"),
@@ -733,12 +734,19 @@ def main():
                      "launches_per_train": getattr(w2, "launches_of_last_solve", None), "kernel": sym,
                      "kernel_ms_bracket": leg["kernel_ms"], "final_translation_error_m": leg["final_translation_error_m"],
                      "timing": "as the headline: trains of K steps bracketed by device synchronisation; median of 3"}
+            entry["roofline"] = {"bound": "hbm", "achieved": b2 / (med * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                 "frac": entry["frac_hbm"], "traffic": None,
+                                 "note": ("resident on chip: no HBM traffic per iteration after the first; the bound is vector-ALU "
+                                          "issue + the in-launch all-reduce (valu_floor_ms)") if b2 <= 200e6 and layout == "flat" else
+                                         "streamed from HBM every iteration"}
             if layout == "indexed":
                 entry["bytes_note"] = ("ADDITIVE voxel-indexed layout: its own bytes (24 B point + 4 B voxel id per point; the 25 MB "
                                        "voxel table is cache resident) — never compared with the 120-byte roofline of the flat "
                                        "layout; the bound is vector-ALU issue (valu_floor_ms)")
             if not args.no_cpu_baseline:
+                t_cpu = time.perf_counter()
                 entry["cpu_baseline"] = cpu_baseline_single(w2, planes if points == n_local and problem != "reproj" else p2, 0.25)
+                cpu_leg_seconds += time.perf_counter() - t_cpu
             other_configs[label] = entry
             d2.close()
             del p2
@@ -925,7 +933,11 @@ def main():
                                   "note": "same precision on both sides; a GPU / CPU ratio says nothing about kernel quality, "
                                           "the roofline fraction does"}
     if stages is not None:
-        result["stages"] = stages
+        # the stage lines are entries of other_configs like the solver configurations (same run, same clock)
+        other_configs.update(stages)
+        result["stage_entries_of_other_configs"] = sorted(stages)
+        import bench_stages
+        result["cpu_seconds_of_the_stage_legs"] = cpu_leg_seconds + bench_stages.CPU_LEG_SECONDS[0]
     # LAST key, <= 1 KB: one [ms, fraction of the stage's bound] pair per line of this run, so that a log tail shows them all
     def sig(x):
         return float("%.4g" % x)
@@ -946,7 +958,7 @@ def main():
              "map_ref_wave", "ingest_10M_records_raw": "ing_raw", "ingest_10M_records_host_pack": "ing_pack", "ingest_10M_planes": "ing_planes"}
     for label, entry in (stages or {}).items():
         if label in short:
-            summary[short[label]] = [sig(entry["ms"]["median"]), sig(entry["frac"])]
+            summary[short[label]] = [sig(entry["ms"]["median"]), sig(entry["roofline"]["frac"])]
     if stages is not None:
         w = stages["reference_wrapper_ndt"]
         summary["wrap_ndt"] = [sig(w["ms"]["median"]), int(w["cost_lines_equal_the_captured_run"])]

@@ -44,13 +44,61 @@ def timed_ms(ctx, fn, reps=3, warm=1):
     return summarize(out)
 
 
-def roof(entry, nbytes, ms, peak_gbps=HBM_PEAK_GBPS, bound="hbm"):
+def roof(entry, nbytes, ms, peak_gbps=HBM_PEAK_GBPS, bound="hbm", traffic=None):
+    """The entry's roofline object, same keys as the headline's: achieved = algorithmic bytes / measured time.
+    traffic = HBM-side bytes per launch of the dominant kernel from the committed stage profile, when there is one."""
     entry["algorithmic_bytes"] = int(nbytes)
-    entry["bound"] = bound
-    entry["achieved_GBps"] = nbytes / (ms * 1e-3) / 1e9
-    entry["peak_GBps"] = peak_gbps
-    entry["frac"] = entry["achieved_GBps"] / peak_gbps
+    achieved = nbytes / (ms * 1e-3) / 1e9
+    entry["roofline"] = {"bound": bound, "achieved": achieved, "peak": peak_gbps, "unit": "GB/s", "frac": achieved / peak_gbps,
+                         "traffic": traffic}
     return entry
+
+
+def stage_traffic(stage, kernel_substring):
+    """HBM-side bytes per launch ((2 x FETCH_SIZE + WRITE_SIZE) KB, separate PMC passes) of a kernel of a committed stage
+    profile (tools/profile_stages.sh → profiles/rNN_<stage>_summary.json), newest round first; None when there is none."""
+    import glob
+    import re
+
+    def order(path):
+        m = re.match(r"r(\d+)([a-z]*)_", os.path.basename(path))
+        return (int(m.group(1)), m.group(2) == "", m.group(2)) if m else (0, False, "")
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_summary.json" % stage)), key=order, reverse=True):
+        try:
+            prof = json.load(open(path))
+        except Exception:  # noqa: BLE001
+            continue
+        for name, k in (prof.get("kernels") or {}).items():
+            if kernel_substring in name and k.get("hbm_side_bytes_per_launch"):
+                return {"bytes": k["hbm_side_bytes_per_launch"], "kernel_avg_us": k.get("avg_us"), "kernel": name.split("(")[0][:80],
+                        "source": os.path.relpath(path, ROOT)}
+    return None
+
+
+def with_traffic(entry, stage, kernel_substring):
+    t = stage_traffic(stage, kernel_substring)
+    if t is not None:
+        entry["roofline"]["traffic"] = t["bytes"]
+        entry["traffic_source"] = ("NOT measured in this run: (2 x FETCH_SIZE + WRITE_SIZE) KB per launch of %s in the committed "
+                                   "profile %s (separate --pmc passes; kernel average there %.1f us)"
+                                   % (t["kernel"], t["source"], t["kernel_avg_us"] or 0.0))
+    return entry
+
+
+CPU_LEG_SECONDS = [0.0]  # wall time of every CPU baseline leg of this process, summed (bench.py reports it; the bar is 10 s)
+
+
+def cpu_leg(fn):
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        t0 = time.perf_counter()
+        try:
+            return fn(*args, **kwargs)
+        finally:
+            CPU_LEG_SECONDS[0] += time.perf_counter() - t0
+    return wrapper
 
 
 def cpu_timed(fn, budget_s, min_passes=1):
@@ -121,6 +169,7 @@ def stage_matcher(ctx, pkg, planes, want_cpu):
     return out
 
 
+@cpu_leg
 def cpu_matcher(means, pts, Rt, tt, sample=400_000):
     from oracle import oracle_scene
     cores = host_threads()
@@ -172,6 +221,7 @@ def stage_mapbuild(ctx, pkg, want_cpu):
     return out
 
 
+@cpu_leg
 def cpu_mapbuild(points, res, what):
     from oracle import oracle_scene
     oracle_scene.build_ndt_map_eigen(points[:20_000], res, max_voxels=1 << 18)
@@ -234,6 +284,7 @@ def stage_ingest(ctx, pkg, planes, want_cpu):
     return out
 
 
+@cpu_leg
 def cpu_pack(rec, sample=2_000_000):
     from oracle import loader as oracle
     sub = rec[:sample]
@@ -279,11 +330,11 @@ def stage_pgo(ctx, pkg, want_cpu):
          "ms_blocking_call": lin_call, "value": M / (lin_ms * 1e-3), "unit": "constraint linearisations/s",
          "timing": "hipEvent pair around 10 back-to-back sweeps (nos_pgo_time_sweep); ms_blocking_call = nos_pgo_linearize "
                    "with its two scalar readbacks"}
-    out["pgo_linearize"] = roof(e, lin_bytes, lin_ms)
+    out["pgo_linearize"] = with_traffic(roof(e, lin_bytes, lin_ms), "pgo", "pgo_linearize_kernel")
     e = {"poses": N, "constraints": M, "ms": {"min": mv_ms, "median": mv_ms, "max": mv_ms, "n": 20},
          "value": M / (mv_ms * 1e-3), "unit": "constraint products/s",
          "timing": "hipEvent pair around 20 back-to-back products of the PCG iteration's kind (in-launch p.Ap sum included)"}
-    out["pgo_matvec"] = roof(e, mv_bytes, mv_ms)
+    out["pgo_matvec"] = with_traffic(roof(e, mv_bytes, mv_ms), "pgo", "pgo_matvec_block_kernel" if E else "pgo_matvec_cg_kernel")
     # one PCG iteration, net of the set-up: two solves with exactly K1 and K2 iterations (tolerance 0)
     k1, k2 = 8, 56
     g.solve(1e-3, k1, 0.0)
@@ -332,6 +383,7 @@ def stage_pgo(ctx, pkg, want_cpu):
     return out
 
 
+@cpu_leg
 def cpu_pgo(synth, n=400):
     from oracle import oracle_pgo
     d = synth.pose_graph(n, 3)
@@ -409,6 +461,7 @@ def stage_reference_wrappers(ctx, pkg, want_cpu):
     return out
 
 
+@cpu_leg
 def cpu_wrapper_ndt(room, local, want):
     from oracle import loader as oracle
     from oracle import oracle_scene as scene
@@ -429,6 +482,7 @@ def cpu_wrapper_ndt(room, local, want):
                       "(numpy, 9 356 points x 96 voxels) + oracle/nos_oracle.c's scalar fp64 LM loop per round"}
 
 
+@cpu_leg
 def cpu_wrapper_reproj(planes, intr):
     from oracle import loader as oracle
     intr4 = (1.0 / intr[0], 1.0 / intr[1], intr[2], intr[3])

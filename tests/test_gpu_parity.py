@@ -743,3 +743,41 @@ def test_bench_line_carries_the_contract_fields():
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
+
+
+@pytest.mark.gpu
+def test_default_bench_line_carries_every_stage_with_roofline_and_cpu_baseline():
+    """`python bench.py` with no flags — the command the driver runs: besides the headline, `other_configs` holds one
+    driver-timed entry per single-GPU configuration and per stage either side of the hot path, each with a
+    roofline object priced on DESIGN.md §3.1's algorithmic bytes; the stages with a CPU baseline of the same work; the
+    reference's two wrappers with their COST lines checked; `summary` is the LAST key and stays below 1 KB; the CPU legs of
+    the stages take ≤ 10 s together."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py")], capture_output=True, text=True, timeout=900, cwd=root)
+    assert run.returncode == 0, run.stderr[-2000:]
+    lines = [l for l in run.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert list(d)[-1] == "summary" and len(json.dumps(d["summary"])) <= 1024
+    oc = d["other_configs"]
+    stages = ["pgo_linearize", "pgo_matvec", "pgo_pcg_iteration", "matcher_10M_unsorted", "matcher_10M_cell_sorted",
+              "matcher_10M_cell_sorted_ids", "ingest_10M_records_raw", "ingest_10M_records_host_pack", "ingest_10M_planes",
+              "mapbuild_10M_100k_voxels", "mapbuild_10M_796k_voxels", "mapbuild_reference_scene_exact",
+              "mapbuild_reference_scene_wave_parallel"]
+    for key in stages:
+        r = oc[key]["roofline"]
+        assert r["bound"] in ("hbm", "pcie") and 0.0 < r["frac"] <= 1.05 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9, key
+        assert oc[key]["algorithmic_bytes"] > 0
+    for key in ("pgo_linearize", "matcher_10M_cell_sorted", "ingest_10M_records_host_pack", "mapbuild_10M_100k_voxels",
+                "mapbuild_reference_scene_exact", "reference_wrapper_ndt", "reference_wrapper_reproj"):
+        c = oc[key]["cpu_baseline"]
+        assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"], key
+    assert oc["reference_wrapper_ndt"]["cost_lines_equal_the_captured_run"] is True
+    assert oc["reference_wrapper_reproj"]["cost_line_equals_the_captured_run"] is True
+    assert oc["pgo_pcg_iteration"]["launches_per_iteration"] <= 6 and oc["pgo_pcg_iteration"]["ms"]["median"] <= 0.55
+    solver = [k for k in oc if k.split(" ")[0] in ("reproj_f64_2M", "ndt6_f64_100k", "ndt6_f32_10M", "ndt3_f64_10M", "indexed_10M")]
+    assert len(solver) == 5 and all("roofline" in oc[k] and "cpu_baseline" in oc[k] for k in solver)
+    assert d["cpu_seconds_of_the_stage_legs"] <= 10.0
