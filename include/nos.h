@@ -131,7 +131,8 @@ int nos_ctx_comm_init_shm(nos_ctx* ctx, int n_ranks, int rank, const char* shm_n
 /* The same communicator with its SLOTS in device memory: every rank allocates its slot buffer as fine-grained device
  * memory, exports it with hipIpcGetMemHandle through the shared-memory segment (which keeps the handshake and control
  * words only) and opens the buffers of its peers; inside the launch a rank then writes its 28 sums and its round number
- * straight into every peer's buffer — device to device, over xGMI between GPUs — and polls only its own memory.  Same
+ * straight into every peer's buffer — device to device (between GPUs of a node presumably over xGMI; not verified on more than
+ * one GPU) — and polls only its own memory.  Same
  * slots, same round numbers, same rank-order sum: bit-identical to the host-memory form.  NOS_ERR_UNSUPPORTED when the
  * platform refuses the fine-grained allocation or the IPC export / import. */
 int nos_ctx_comm_init_shm_device(nos_ctx* ctx, int n_ranks, int rank, const char* shm_name);
