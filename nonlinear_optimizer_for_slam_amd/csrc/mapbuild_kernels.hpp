@@ -123,20 +123,23 @@ struct MapBuildParams {
                          //    eigenvector signs and to rotations inside degenerate eigenspaces)
 };
 
-// One wave per voxel.  seg_offset[v] .. seg_offset[v] + seg_count[v] index into sorted_idx.
-__global__ __launch_bounds__(256) void voxel_stats_kernel(const double* __restrict__ px, const double* __restrict__ py,
-                                                          const double* __restrict__ pz,
-                                                          const uint32_t* __restrict__ sorted_idx,
-                                                          const uint32_t* __restrict__ seg_offset,
-                                                          const uint32_t* __restrict__ seg_count, uint32_t n_voxels,
-                                                          MapBuildParams prm, double* __restrict__ mean_out,
-                                                          double* __restrict__ sqrt_info_out,
-                                                          unsigned char* __restrict__ valid_out) {
+// Two kernels since round 4.  In the one-kernel form lane 0 of every wave ran the 3x3 eigen-decomposition while 63 lanes
+// idled: at 796 k voxels of ≈ 12 points that was 3.0 of the build's 12 ms (profiles/r04_mapbuild_summary.json: issue stalls
+// 46 %, one launch 3 041 µs).  Same additions in the same order, same eigen routine.
+//
+// (1) One wave per voxel: count / sum / moment in a fixed order.  seg_offset[v] .. + seg_count[v] index into sorted_idx.
+//     acc_out: [n_voxels][9] = sx sy sz | mxx mxy mxz myy myz mzz.
+__global__ __launch_bounds__(256) void voxel_sums_kernel(const double* __restrict__ px, const double* __restrict__ py,
+                                                         const double* __restrict__ pz,
+                                                         const uint32_t* __restrict__ sorted_idx,
+                                                         const uint32_t* __restrict__ seg_offset,
+                                                         const uint32_t* __restrict__ seg_count, uint32_t n_voxels,
+                                                         double* __restrict__ acc_out) {
   const uint32_t v = (blockIdx.x * 256 + threadIdx.x) / kWave;
   const int lane = threadIdx.x & (kWave - 1);
   if (v >= n_voxels) return;  // wave-uniform
   const uint32_t begin = seg_offset[v], count = seg_count[v];
-  double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // sx sy sz | mxx mxy mxz myy myz mzz
+  double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (uint32_t k = lane; k < count; k += kWave) {
     const uint32_t i = sorted_idx[begin + k];
     const double x = px[i], y = py[i], z = pz[i];
@@ -152,7 +155,27 @@ __global__ __launch_bounds__(256) void voxel_stats_kernel(const double* __restri
   }
 #pragma unroll
   for (int k = 0; k < 9; ++k) acc[k] = wave_sum(acc[k]);
-  if (lane != 0) return;
+  if (lane < 9) {  // lane k stores sum k (every lane holds all nine after the butterfly)
+    double mine = acc[0];
+#pragma unroll
+    for (int k = 1; k < 9; ++k) mine = lane == k ? acc[k] : mine;
+    acc_out[9 * size_t(v) + lane] = mine;
+  }
+}
+
+// (2) One LANE per voxel: mean, covariance (the moment starts at identity, MDM/types.h:14), eigen-decomposition, validity
+//     rules, sqrt-information.
+__global__ __launch_bounds__(256) void voxel_eigen_kernel(const double* __restrict__ acc_in,
+                                                          const uint32_t* __restrict__ seg_count, uint32_t n_voxels,
+                                                          MapBuildParams prm, double* __restrict__ mean_out,
+                                                          double* __restrict__ sqrt_info_out,
+                                                          unsigned char* __restrict__ valid_out) {
+  const uint32_t v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= n_voxels) return;
+  const uint32_t count = seg_count[v];
+  double acc[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) acc[k] = acc_in[9 * size_t(v) + k];
   double S[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   double mean[3] = {0, 0, 0};
   unsigned char ok = 0;

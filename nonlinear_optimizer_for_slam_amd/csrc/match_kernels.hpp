@@ -158,93 +158,6 @@ __device__ __forceinline__ void find_two_nearest(const MapView& map, double qx, 
       }
 }
 
-// The search of a whole 256-thread workgroup, with the points re-dealt to the lanes in MAP-cell order first (round 4).
-// What bounds the lane-per-point search (profiles/r04_match_summary.json): not HBM and not arithmetic but the vector L1 — 66
-// line accesses per point; a 16-byte load is coalesced per quarter wave only, and the 16 lanes of a quarter sit in ≈ 8
-// different map cells, because the scan is sorted by cell in ITS OWN frame and the pose turns that order against the map's
-// grid.  So the workgroup sorts its 256 points by map cell among themselves (bitonic network in LDS on {cell index relative to
-// the workgroup's bounding box | lane}: 36 stages, ≈ 3 k cycles), every lane runs the unchanged find_two_nearest for the point
-// it was dealt — the lanes of a quarter wave now share one or two cells, i.e. the same candidate records and the same trip
-// counts — and hands the two positions back to the point's own lane through LDS.  Each point's search is the same sequence of
-// operations as before, so the results are identical.  A workgroup whose bounding box has more than 65 536 cells (an unsorted
-// scan) keeps its points where they are.  Must be called by all 256 threads (`active` = has a point).
-__device__ __forceinline__ void find_two_nearest_block(const MapView& map, bool active, double qx, double qy, double qz,
-                                                       uint32_t (&best_j)[2]) {
-  __shared__ int box[6];          // min x, y, z | max x, y, z of the reachable points' cells
-  __shared__ uint32_t skey[256];
-  __shared__ double sq[3][256];
-  __shared__ uint32_t sres[2][256];
-  const uint32_t t = threadIdx.x;
-  best_j[0] = best_j[1] = 0xFFFFFFFFu;
-  if (map.dense_begin == nullptr) {  // hash-table maps: no grid to sort by
-    if (active) {
-      TwoNearest best;
-      find_two_nearest(map, qx, qy, qz, best);
-      best_j[0] = best.j[0];
-      best_j[1] = best.j[1];
-    }
-    return;
-  }
-  const int64_t rx64 = int64_t(floor(qx * map.inv_cell)) - map.ox;
-  const int64_t ry64 = int64_t(floor(qy * map.inv_cell)) - map.oy;
-  const int64_t rz64 = int64_t(floor(qz * map.inv_cell)) - map.oz;
-  // a point whose 27-cell neighbourhood misses the grid has no candidate at all: it takes no part
-  const bool reach = active && rx64 >= -1 && rx64 <= map.nx && ry64 >= -1 && ry64 <= map.ny && rz64 >= -1 && rz64 <= map.nz;
-  const int rx = int(rx64), ry = int(ry64), rz = int(rz64);
-  if (t < 3) box[t] = 0x7FFFFFFF;
-  if (t >= 3 && t < 6) box[t] = -0x7FFFFFFF;
-  __syncthreads();
-  if (reach) {
-    atomicMin(&box[0], rx);
-    atomicMin(&box[1], ry);
-    atomicMin(&box[2], rz);
-    atomicMax(&box[3], rx);
-    atomicMax(&box[4], ry);
-    atomicMax(&box[5], rz);
-  }
-  sq[0][t] = qx;
-  sq[1][t] = qy;
-  sq[2][t] = qz;
-  __syncthreads();
-  const int bx = box[0], by = box[1], bz = box[2];
-  const int64_t dx = int64_t(box[3]) - bx + 1, dy = int64_t(box[4]) - by + 1, dz = int64_t(box[5]) - bz + 1;
-  const bool any = box[3] >= bx;                                  // block-uniform: somebody reaches the grid
-  const bool sorted = any && dx * dy * dz <= 65536;               // block-uniform
-  uint32_t mine = t;  // the lane whose point this lane searches for
-  bool search = reach;
-  if (sorted) {
-    const uint32_t rel = reach ? uint32_t((int64_t(rx - bx) * dy + (ry - by)) * dz + (rz - bz)) : 0xFFFFFFu;
-    skey[t] = (rel << 8) | t;
-    for (uint32_t k = 2; k <= 256; k <<= 1)
-      for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-        __syncthreads();
-        const uint32_t partner = t ^ j;
-        const uint32_t a = skey[t], b = skey[partner];
-        const bool ascending = (t & k) == 0;
-        const uint32_t keep = ((t < partner) == ascending) ? (a < b ? a : b) : (a < b ? b : a);
-        __syncthreads();
-        skey[t] = keep;
-      }
-    __syncthreads();
-    const uint32_t sk = skey[t];
-    mine = sk & 0xFFu;
-    search = (sk >> 8) != 0xFFFFFFu;
-  }
-  TwoNearest best;
-  best.init();
-  if (search) find_two_nearest(map, sq[0][mine], sq[1][mine], sq[2][mine], best);
-  if (!sorted) {
-    best_j[0] = best.j[0];
-    best_j[1] = best.j[1];
-    return;
-  }
-  sres[0][mine] = best.j[0];
-  sres[1][mine] = best.j[1];
-  __syncthreads();
-  best_j[0] = sres[0][t];
-  best_j[1] = sres[1][t];
-}
-
 // One thread per scan point.  points: 3 planes of n doubles (local frame).
 template <typename DST>
 __global__ __launch_bounds__(256) void match_kernel(MapView map, const double* __restrict__ px,
@@ -255,15 +168,14 @@ __global__ __launch_bounds__(256) void match_kernel(MapView map, const double* _
                                                     unsigned long long* __restrict__ n_matches) {
   const uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x;
   int found = 0;
-  const bool active = i < n_points;
-  const uint64_t ic = active ? i : 0;
-  const double x = px[ic], y = py[ic], z = pz[ic];
-  const double qx = pose.R[0] * x + pose.R[1] * y + pose.R[2] * z + pose.t[0];
-  const double qy = pose.R[3] * x + pose.R[4] * y + pose.R[5] * z + pose.t[1];
-  const double qz = pose.R[6] * x + pose.R[7] * y + pose.R[8] * z + pose.t[2];
-  uint32_t best_j[2];
-  find_two_nearest_block(map, active, qx, qy, qz, best_j);  // the whole workgroup goes in
-  if (active) {
+  if (i < n_points) {
+    const double x = px[i], y = py[i], z = pz[i];
+    const double qx = pose.R[0] * x + pose.R[1] * y + pose.R[2] * z + pose.t[0];
+    const double qy = pose.R[3] * x + pose.R[4] * y + pose.R[5] * z + pose.t[1];
+    const double qz = pose.R[6] * x + pose.R[7] * y + pose.R[8] * z + pose.t[2];
+    TwoNearest best;
+    find_two_nearest(map, qx, qy, qz, best);
+    const uint32_t (&best_j)[2] = best.j;
     // two consecutive slots 2i, 2i+1 → one 2-wide store per field
     const uint64_t i0 = 2 * i;
     const uint64_t off = (i0 >> L.tile_shift) * L.tile_stride + (i0 & L.tile_mask);

@@ -194,15 +194,14 @@ __global__ __launch_bounds__(256) void match_index_kernel(nos::MapView map, cons
                                                           unsigned long long* __restrict__ n_matches) {
   const uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x;
   int found = 0;
-  const bool active = i < n_points;
-  const uint64_t ic = active ? i : 0;
-  const double x = px[ic], y = py[ic], z = pz[ic];
-  const double qx = pose.R[0] * x + pose.R[1] * y + pose.R[2] * z + pose.t[0];
-  const double qy = pose.R[3] * x + pose.R[4] * y + pose.R[5] * z + pose.t[1];
-  const double qz = pose.R[6] * x + pose.R[7] * y + pose.R[8] * z + pose.t[2];
-  uint32_t best_j[2];
-  nos::find_two_nearest_block(map, active, qx, qy, qz, best_j);  // the whole workgroup goes in
-  if (active) {
+  if (i < n_points) {
+    const double x = px[i], y = py[i], z = pz[i];
+    const double qx = pose.R[0] * x + pose.R[1] * y + pose.R[2] * z + pose.t[0];
+    const double qy = pose.R[3] * x + pose.R[4] * y + pose.R[5] * z + pose.t[1];
+    const double qz = pose.R[6] * x + pose.R[7] * y + pose.R[8] * z + pose.t[2];
+    nos::TwoNearest best;
+    nos::find_two_nearest(map, qx, qy, qz, best);
+    const uint32_t (&best_j)[2] = best.j;
     const bool ok0 = best_j[0] != 0xFFFFFFFFu, ok1 = best_j[1] != 0xFFFFFFFFu && max_neighbors > 1;
     idx0[i] = ok0 ? int32_t(best_j[0]) : -1;
     idx1[i] = ok1 ? int32_t(best_j[1]) : -1;

@@ -203,10 +203,15 @@ int nos_ndt_map_build(nos_ctx* ctx, size_t n_points, const double* points_xyz, d
                            ctx->settings.map_eigen_version, d_acc, d_mean, d_S, d_valid, d_evals, d_evecs, d_first, st);
   } else if (e == hipSuccess && V > 0) {
     const nos::MapBuildParams prm{5, 0.01, 0.01, (flags & NOS_MAP_PROPER_SQRT_INFORMATION) ? 1 : 0};
-    const unsigned blocks = unsigned((size_t(V) * nos::kWave + 255) / 256);
-    hipLaunchKernelGGL(nos::voxel_stats_kernel, dim3(blocks), dim3(256), 0, st, px, py, pz, idx_sorted, offsets, counts, V,
-                       prm, d_mean, d_S, d_valid);
-    e = hipGetLastError();
+    e = buf.alloc(&d_acc, size_t(V) * 9);
+    if (e == hipSuccess) {
+      const unsigned blocks = unsigned((size_t(V) * nos::kWave + 255) / 256);
+      hipLaunchKernelGGL(nos::voxel_sums_kernel, dim3(blocks), dim3(256), 0, st, px, py, pz, idx_sorted, offsets, counts, V,
+                         d_acc);
+      hipLaunchKernelGGL(nos::voxel_eigen_kernel, dim3(unsigned((size_t(V) + 255) / 256)), dim3(256), 0, st, d_acc, counts, V,
+                         prm, d_mean, d_S, d_valid);
+      e = hipGetLastError();
+    }
   }
   // The statistics stay on the device for the matcher's tables (map_create_device: bucketing by matcher cell, dense grid
   // and hash table are built there); they travel to the host only for the caller's nos_map_stats and for the reference-exact
