@@ -942,8 +942,16 @@ __global__ __launch_bounds__(256) void pgo_apply_precond_kernel(const double* __
   if (t < n_poses) {
     double ri[6], M[6][6];
     int k = 0;
+    using V2 = double __attribute__((ext_vector_type(2)));
+    {  // the row's six entries as three 16-byte pieces
+      const V2* r2 = reinterpret_cast<const V2*>(r) + size_t(3) * t;
 #pragma unroll
-    for (int a = 0; a < 6; ++a) ri[a] = r[size_t(6) * t + a];
+      for (int a = 0; a < 3; ++a) {
+        const V2 v = r2[a];
+        ri[2 * a] = v[0];
+        ri[2 * a + 1] = v[1];
+      }
+    }
 #pragma unroll
     for (int a = 0; a < 6; ++a)
 #pragma unroll
@@ -968,15 +976,19 @@ __global__ __launch_bounds__(256) void pgo_apply_precond_kernel(const double* __
 #pragma unroll
       for (int a = 0; a < 3; ++a) corr[3 + a] = R[a] * xa[3] + R[3 + a] * xa[4] + R[6 + a] * xa[5];  // R^T theta
     }
+    double zi[6];
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
       double v = corr[a];
 #pragma unroll
       for (int b = 0; b < 6; ++b) v += M[a][b] * ri[b];
-      z[size_t(6) * t + a] = v;
+      zi[a] = v;
       rz += ri[a] * v;
       rr += ri[a] * ri[a];
     }
+    V2* z2 = reinterpret_cast<V2*>(z) + size_t(3) * t;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) z2[a] = V2{zi[2 * a], zi[2 * a + 1]};
   } else if (t - n_poses < n_edges) {
     const uint32_t e = t - n_poses;
     const double v = rs[e] / (h_s[e] * (1.0 + lambda));

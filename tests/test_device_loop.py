@@ -452,7 +452,8 @@ def test_a_real_give_up_is_remembered_for_a_while_and_reported(ctx):
 
 @pytest.mark.parametrize("kind,dtype,n", [
     ("ndt6", "f64", 131_073),     # 2 per lane (registers only)
-    ("ndt6", "f64", 500_000),     # 4 per lane: 2 in registers + 2 in LDS — the capacity of the fp64 NDT shape
+    ("ndt6", "f64", 500_000),     # 4 per lane
+    ("ndt6", "f64", 786_432),     # 6 per lane: 3 in registers + 3 in LDS — the capacity of the fp64 NDT shape (A-form items)
     ("ndt3", "f64", 400_001),
     ("ndt6", "f32", 900_000),     # 7 per lane: 3 + 4
     ("reproj", "f64", 2_000_000),  # BASELINE.json configs[2]: 16 per lane, 9 in registers + 7 in LDS
