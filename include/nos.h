@@ -134,7 +134,12 @@ int nos_ctx_comm_init_shm(nos_ctx* ctx, int n_ranks, int rank, const char* shm_n
  * straight into every peer's buffer — device to device (between GPUs of a node presumably over xGMI; not verified on more than
  * one GPU) — and polls only its own memory.  Same
  * slots, same round numbers, same rank-order sum: bit-identical to the host-memory form.  NOS_ERR_UNSUPPORTED when the
- * platform refuses the fine-grained allocation or the IPC export / import. */
+ * platform refuses the fine-grained allocation or the IPC export / import.
+ * With this communicator nos_*_solve keeps the whole LM loop in ONE launch on every rank: the exchange is a third stage of the
+ * in-launch all-reduce (8-byte {tag | half} granules pushed into the peers' buffers, bounded wait of 8 s).  If a rank has to
+ * give up (GPU shared with other processes), all ranks abandon that launch together, redo the solve with one launch per
+ * iteration (nos_lm_report.fallback = 1) and pause the one-launch form for the next 64 solves, doubling on repeats — counted
+ * in solves so that all ranks switch back in the same call. */
 int nos_ctx_comm_init_shm_device(nos_ctx* ctx, int n_ranks, int rank, const char* shm_name);
 int nos_comm_shm_unlink(const char* shm_name);
 /* Leaves whichever communicator the context has (collective for RCCL); nos_ctx_destroy does it implicitly. */

@@ -174,9 +174,15 @@ __attribute__((unused)) static __global__ __launch_bounds__(256) void index_sort
   ids[i] = uint32_t(i);
 }
 
-// after a one-launch solve with an in-launch exchange gave up: the rounds it may have used are never used again
+// After a one-launch solve with an in-launch exchange gave up: the rounds it may have used are never used again (every rank
+// skips the same number).  round[1] = the last round of a PATIENT exchange: the ranks abandon a launch up to one in-launch
+// time-out apart, so the first exchanges of the loop that redoes the solve wait four times as long for each other as usual
+// (mailbox_allreduce) before they call a peer missing.
 __attribute__((unused)) static __global__ void mailbox_skip_rounds_kernel(unsigned long long* round, unsigned long long n) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) *round += n;
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    round[0] += n;
+    round[1] = round[0] + 2ull;
+  }
 }
 
 }  // namespace nos

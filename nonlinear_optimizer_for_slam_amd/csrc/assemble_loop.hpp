@@ -54,7 +54,8 @@ struct Mailbox {
   double* base;                 // device address of the shared mailbox: [n_ranks][2][kMailSlotDoubles]; null = no exchange
   double* const* peers;         // device-memory form: peers[r] = rank r's [n_ranks][2][kMailSlotDoubles] buffer (fine-grained
                                 // device memory, peers[rank] is local); null = the slots behind `base` (host memory)
-  unsigned long long* round;    // device word: rounds completed by this rank (all ranks run the same sequence)
+  unsigned long long* round;    // device words: [0] rounds completed by this rank (all ranks run the same sequence),
+                                // [1] rounds up to this one wait four times as long (set after an abandoned one-launch solve)
   unsigned int* error_host;     // host-mapped word set to 1 when a peer did not arrive in time
   int n_ranks;
   int rank;
@@ -80,14 +81,16 @@ struct FusedFinal {
 // block must call it.  Returns the sum over ranks (valid in threads < NOUT).
 template <int NOUT>
 __device__ __forceinline__ double mailbox_allreduce(const Mailbox& mb, double tot, bool* failed = nullptr) {
-  __shared__ unsigned long long s_round;
+  __shared__ unsigned long long s_round, s_patient_until;
   __shared__ int s_failed;
   if (threadIdx.x == 0) {
-    s_round = *mb.round + 1ull;
+    s_round = mb.round[0] + 1ull;
+    s_patient_until = mb.round[1];
     s_failed = 0;
   }
   __syncthreads();
   const unsigned long long round = s_round;
+  const unsigned long long patience = round <= s_patient_until ? 4ull * kMailboxTimeoutTicks : kMailboxTimeoutTicks;
   const size_t parity = size_t(round & 1ull);
   NOS_PROBE(unsigned long long tm0 = wall_clock64(), tm1 = 0, tm2 = 0;)
   // Host-memory form: every rank stores into ITS slot of the one shared segment and polls the others' slots there.
@@ -120,7 +123,7 @@ __device__ __forceinline__ double mailbox_allreduce(const Mailbox& mb, double to
     if (int(threadIdx.x) < mb.n_ranks) {
       const unsigned long long* flag = reinterpret_cast<const unsigned long long*>(
           local + (size_t(threadIdx.x) * 2 + parity) * kMailSlotDoubles + 32);
-      const unsigned long long deadline = wall_clock64() + kMailboxTimeoutTicks;
+      const unsigned long long deadline = wall_clock64() + patience;
       while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != round) {
         if (wall_clock64() > deadline) {  // a peer is missing: report, do not hang
           __hip_atomic_store(mb.error_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -134,6 +134,11 @@ __global__ __launch_bounds__(BLOCK) void solve_single_block_kernel(TiledLayout L
 // per iteration.
 constexpr uint32_t kClusterMaxBlocks = 256;
 constexpr unsigned long long kClusterTimeoutTicks = 5000000ull;  // 50 ms of the 100 MHz wall clock per iteration
+// With the cross-rank exchange inside the launch (stage 3) a wait also covers the peers' skew — processes reach their first
+// launch seconds apart (3 ranks of the test suite: more than 2 s) — so it is as long as the launch-per-iteration exchange's.
+// After a give-up the ranks enter the fall-back loop up to this far apart; its first exchanges therefore wait four times as
+// long (mailbox_skip_rounds_kernel / mailbox_allreduce).
+constexpr unsigned long long kClusterMailboxTimeoutTicks = kMailboxTimeoutTicks;
 
 // Control words of one resident launch, zeroed by the host before the launch (hipMemsetAsync on the launch stream).
 struct ClusterCtl {
@@ -442,7 +447,7 @@ __global__ __launch_bounds__(BLOCK) void solve_cluster_kernel(TiledLayout L, typ
       }
       NOS_RES_STAMP(1)  // block reduce + units issued
       // (several ranks: a wait inside this GPU also covers the time the slowest peer needs to get here — the exchange's bound)
-      const unsigned long long deadline = wall_clock64() + (multi ? kMailboxTimeoutTicks : kClusterTimeoutTicks);
+      const unsigned long long deadline = wall_clock64() + (multi ? kClusterMailboxTimeoutTicks : kClusterTimeoutTicks);
       // bounded spin on one unit; returns false when the launch is being abandoned
       auto await = [&](const TaggedUnit* u, double* value) -> bool {
         unsigned int polls = 0;
@@ -500,7 +505,7 @@ __global__ __launch_bounds__(BLOCK) void solve_cluster_kernel(TiledLayout L, typ
         // system-scope stores are single transactions on every path, so a granule is either the old or the new one and
         // needs no separate flag (cdna_hip_programming.md Guideline 16, R2).  Slots are double buffered by round parity
         // (a rank can be one round ahead of a peer that is still reading, not two).  The wait is bounded like the
-        // launch-per-iteration exchange's (kMailboxTimeoutTicks); a rank that has to give up says so to its peers through
+        // launch-per-iteration exchange's (kClusterMailboxTimeoutTicks, above); a rank that has to give up says so to its peers through
         // granule 63 of its slot, so that they give up with it instead of waiting for sums that will not come.
         TaggedUnit* const global_units = group_units + size_t(2) * 8 * 32;  // [2][32]
         if (blockIdx.x == 0) {
@@ -537,7 +542,7 @@ __global__ __launch_bounds__(BLOCK) void solve_cluster_kernel(TiledLayout L, typ
               }
               double sum = 0.0;
               bool lost = false;
-              const unsigned long long give_up_at = wall_clock64() + kMailboxTimeoutTicks;
+              const unsigned long long give_up_at = wall_clock64() + kClusterMailboxTimeoutTicks;
               for (int r = 0; r < mb.n_ranks && !lost; ++r) {
                 const unsigned long long* slot_r = own + (size_t(r) * 2 + parity) * kMailSlotDoubles;
                 unsigned long long got = 0ull;

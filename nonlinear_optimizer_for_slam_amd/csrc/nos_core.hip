@@ -782,11 +782,18 @@ int lm_solve(nos_dataset* ds, const Request& rq, const nos_lm_options* opt, doub
   const bool stream_form = !resident_fits && (ctx->settings.lm_cluster == 1 || ctx->settings.lm_cluster == 5) && items_per_lane >= 1 &&
                            sh.layout.n_padded % stream_chunk == 0 && sh.layout.n_padded / stream_chunk < (size_t(1) << 31) &&
                            (sh.layout.tile_stride == 0 || (size_t(sh.layout.tile_mask) + 1) % stream_chunk == 0);
-  if (slot.cluster_gave_up &&
-      std::chrono::steady_clock::now() - slot.cluster_gave_up_at > std::chrono::milliseconds(ctx->settings.lm_cluster_retry_ms))
-    slot.cluster_gave_up = false;  // try the one-launch form again
+  bool paused = false;
+  if (mailbox_in_launch) {
+    paused = slot.cluster_paused_solves > 0;  // the same count on every rank (see DeviceSlot)
+    if (paused) --slot.cluster_paused_solves;
+  } else {
+    if (slot.cluster_gave_up &&
+        std::chrono::steady_clock::now() - slot.cluster_gave_up_at > std::chrono::milliseconds(ctx->settings.lm_cluster_retry_ms))
+      slot.cluster_gave_up = false;  // try the one-launch form again
+    paused = slot.cluster_gave_up;
+  }
   if (ds->kind != kKindNdtIndexed && !with_comm && (ctx->shm_dev == nullptr || mailbox_in_launch) && opt->max_iterations > 0 &&
-      cluster_blocks >= 1 && (resident_fits || stream_form) && !slot.cluster_gave_up &&
+      cluster_blocks >= 1 && (resident_fits || stream_form) && !paused &&
       ctx->settings.lm_cluster != 0 && (opt->cost_history == nullptr || opt->max_iterations <= kHistCapacity)) {
     SingleBlockArgs cl{};
     cl.cluster_blocks = int(cluster_blocks);
@@ -837,6 +844,7 @@ int lm_solve(nos_dataset* ds, const Request& rq, const nos_lm_options* opt, doub
     }
     if (finished) {
       __atomic_thread_fence(__ATOMIC_ACQUIRE);
+      slot.cluster_next_pause = 64;
       const double* e = slot.h_log;
       for (int k = 0; k < 9; ++k) st.R[k] = e[nos::kLogR + k];
       for (int k = 0; k < 3; ++k) st.t[k] = e[nos::kLogT + k];
@@ -877,8 +885,13 @@ int lm_solve(nos_dataset* ds, const Request& rq, const nos_lm_options* opt, doub
     // and the text of its refusal is dropped: the call goes on to succeed.
     fell_back = 1;
     if (launched_ok && ctx->settings.debug_cluster_abort != 1) {
-      slot.cluster_gave_up = true;
-      slot.cluster_gave_up_at = std::chrono::steady_clock::now();
+      if (mailbox_in_launch) {
+        slot.cluster_paused_solves = slot.cluster_next_pause;
+        slot.cluster_next_pause = std::min(slot.cluster_next_pause * 2, 65536);
+      } else {
+        slot.cluster_gave_up = true;
+        slot.cluster_gave_up_at = std::chrono::steady_clock::now();
+      }
     }
     if (!launched_ok) clear_last_error();
     if (mailbox_in_launch) {
@@ -1507,6 +1520,8 @@ int nos_ctx_create(const int* device_ids, int n_devices, nos_ctx** out_ctx) {
 
 int nos_ctx_comm_destroy(nos_ctx* ctx) {
   nosd::CtxGuard guard_(ctx);  // one solve / accumulate / create at a time per context
+  if (ctx)
+    for (DeviceSlot& sl : ctx->slots) sl.cluster_paused_solves = 0, sl.cluster_next_pause = 64;  // a new communicator starts with every rank unpaused
   if (!ctx) return NOS_OK;
   if (ctx->comm != nullptr) {
     if (!ctx->slots.empty()) {
@@ -2113,8 +2128,8 @@ int comm_init_mailbox(nos_ctx* ctx, int n_ranks, int rank, const char* shm_name,
   }
   unsigned long long* d_round = nullptr;
   if (e == hipSuccess) {
-    e = hipMalloc(reinterpret_cast<void**>(&d_round), sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMemset(d_round, 0, sizeof(unsigned long long));
+    e = hipMalloc(reinterpret_cast<void**>(&d_round), 2 * sizeof(unsigned long long));  // [0] round, [1] patient-until round
+    if (e == hipSuccess) e = hipMemset(d_round, 0, 2 * sizeof(unsigned long long));
     if (e != hipSuccess) (void)hipHostUnregister(host);
   }
   if (e != hipSuccess) {

@@ -117,6 +117,11 @@ struct DeviceSlot {
   const void* last_kernel = nullptr;  // host function of the hot-path kernel launched last on this device (nos_ctx_last_kernel)
   bool cluster_gave_up = false;  // the last one-launch solve on this device timed out waiting for its grid (shared GPU)
   std::chrono::steady_clock::time_point cluster_gave_up_at{};
+  // Ranks of a device-memory mailbox communicator must agree on the loop form of every solve (the one-launch loop and the
+  // launch-per-iteration loop exchange through different protocols), so there the pause after a give-up is counted in
+  // SOLVES — every rank gives up in the same solve and counts the same calls — not in wall time.
+  int cluster_paused_solves = 0;
+  int cluster_next_pause = 64;  // doubles with every give-up in a row (up to 65 536 solves), back to 64 after a one-launch solve that finished
   std::vector<hipEvent_t> prof_events;
   size_t prof_used = 0;
   bool prof_on = false;

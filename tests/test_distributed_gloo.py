@@ -221,6 +221,58 @@ def test_one_launch_loop_with_the_exchange_inside_the_launch(tmp_path, world, n)
     np.testing.assert_allclose(one[0]["cost"], per[0]["cost"], rtol=1e-12)
 
 
+def _mailbox_give_up_worker(rank, world, name, out_dir):
+    import numpy as np
+    from nonlinear_optimizer_for_slam_amd import Context, NdtDataset, distributed, synth
+    loss = ("exponential", 1.0, 1.0)
+    ctx = Context((0,))
+    ctx.comm_init_shm(world, rank, name, device_memory=True)
+    ctx.set_option("lm_cluster_max_blocks", max(1, 256 // world))
+    n = 60_000
+    planes = synth.ndt_planes(n, 1500)
+    lo, hi = distributed.shard_range(n, rank, world)
+    ds = NdtDataset.from_planes(ctx, np.ascontiguousarray(planes[:, lo:hi]), "f64")
+    rows = []
+    for k in range(70):
+        if k == 2:
+            ctx.set_option("debug_cluster_abort", 2)   # this launch finds `abort` raised on EVERY rank: a collective give-up
+        R, t, rep = ds.solve6(np.eye(3), np.zeros(3), loss, max_iterations=30)
+        if k == 2:
+            ctx.set_option("debug_cluster_abort", 0)
+        rows.append([rep["launches"], rep["fallback"], rep["iterations"], *R.reshape(-1), *t])
+        if k in (1, 2, 40):                             # the other protocol in between: accumulates share the round counter
+            ds.accumulate6(np.eye(3), [0.01, 0.02, 0.03], loss)
+    np.save(os.path.join(out_dir, "give_up_rank%d.npy" % rank), np.array(rows))
+    ds.close()
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_ranks_give_up_pause_and_return_to_the_one_launch_loop_together(tmp_path):
+    """The one-launch loop and the launch-per-iteration loop exchange through different protocols, so the ranks of a
+    device-memory mailbox must pick the same form for EVERY solve.  Solve 2 is abandoned on both ranks (test hook): it is
+    redone launch by launch (fallback = 1, same result), the next 64 solves stay in that form on both ranks — a count of
+    solves, not a time: processes' clocks differ, their call counts do not — and solve 67 is back in one launch.  Every solve
+    gives the same pose on both ranks, to rounding the same in both forms."""
+    import uuid
+    from nonlinear_optimizer_for_slam_amd import api
+    world = 2
+    name = "/nos_test_%s" % uuid.uuid4().hex
+    try:
+        mp.spawn(_mailbox_give_up_worker, args=(world, name, str(tmp_path)), nprocs=world, join=True)
+    finally:
+        api.shm_unlink(name)
+    a, b = (np.load(tmp_path / ("give_up_rank%d.npy" % r)) for r in range(world))
+    assert np.array_equal(a, b)                                     # launches, fallback flags, iterations, poses: identical
+    launches, fallback = a[:, 0], a[:, 1]
+    assert list(launches[:2]) == [1, 1] and list(fallback[:2]) == [0, 0]
+    assert launches[2] > 1 and fallback[2] == 1                     # the abandoned solve, redone
+    assert np.all(launches[3:67] > 1) and np.all(fallback[3:67] == 0)  # paused: 64 solves, by choice, not by failure
+    assert np.all(launches[67:] == 1) and np.all(fallback[67:] == 0)
+    assert np.all(a[:, 2] == a[0, 2])
+    np.testing.assert_allclose(a[:, 3:], np.broadcast_to(a[0, 3:], a[:, 3:].shape), rtol=0, atol=1e-11)
+
+
 def _mailbox_lonely_worker(rank, name, out_dir):
     import numpy as np
     from nonlinear_optimizer_for_slam_amd import Context, NdtDataset, _lib, synth

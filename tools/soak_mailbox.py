@@ -31,6 +31,8 @@ def worker(rank, world, name, rounds, out_dir, form="host"):
         sets[n] = NdtDataset.from_planes(ctx, np.ascontiguousarray(planes[:, lo:hi]), "f64")
     first = {}
     for r in range(rounds):   # a fixed count on every rank: the exchange is collective
+        if rank == 0 and r % 2000 == 0 and r:
+            print("  round %d, fallbacks on rank 0 so far: %d" % (r, fallbacks), flush=True)
         for n, ds in sets.items():
             R, t, rep = ds.solve6(np.eye(3), np.zeros(3), EXP, max_iterations=20)
             fallbacks += int(rep.get("fallback", 0))
