@@ -4,6 +4,9 @@
 // the kernels in assemble_kernels.hpp.  There is no CPU fallback: without a usable HIP device every entry point
 // fails with NOS_ERR_NO_DEVICE / NOS_ERR_HIP.
 #include "nos_internal.hpp"
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+#include <emmintrin.h>  // full-line non-temporal stores of the host-pack ingestion
+#endif
 
 #include <cxxabi.h>
 
@@ -1209,20 +1212,58 @@ int zero_pad_launch(int n_fields, const nos::TiledLayout& L, void* dst, hipStrea
 // `pinned` is the staging image of one chunk: planar (tile_log2 = 0: field f of record j at f * chunk + j) or in the
 // dataset's tiled order (record j of the chunk at (j >> T) * n_fields * 2^T + f * 2^T + (j mod 2^T); chunks start on
 // tile boundaries), so that the image is one contiguous piece of the dataset.  [lo, lo + count) = this thread's records.
+// Records are taken a cache line of OUTPUT at a time (8 doubles / 16 floats per field): the line's worth of every field is
+// gathered into a small block first and leaves with full-line non-temporal stores — the staging image is written once and
+// read only by the copy engine, so the destination lines need not be fetched for ownership first (4.2 instead of 5.4 GB of
+// host memory traffic per 10 M NDT records) and 15 interleaved 8-byte store streams do not fight over the core's
+// write-combining buffers.
 template <typename T>
 void pack_range(const unsigned char* host, size_t stride, const nos::FieldOffsets& fo, int n_fields, size_t first, size_t lo,
                 size_t count, size_t chunk, int tile_log2, T* pinned) {
   const size_t tile = size_t(1) << tile_log2, mask = tile - 1;
-  for (size_t j = lo; j < lo + count; ++j) {
+  const size_t pitch = tile_log2 == 0 ? chunk : tile;
+  auto dst_of = [&](size_t j) -> T* {
+    return tile_log2 == 0 ? pinned + j : pinned + (j >> tile_log2) * (tile * size_t(n_fields)) + (j & mask);
+  };
+  auto one = [&](size_t j) {
     const unsigned char* rec = host + (first + j) * stride;
-    T* dst = tile_log2 == 0 ? pinned + j : pinned + (j >> tile_log2) * (tile * size_t(n_fields)) + (j & mask);
-    const size_t pitch = tile_log2 == 0 ? chunk : tile;
+    T* dst = dst_of(j);
     for (int f = 0; f < n_fields; ++f) {
       double v;
       memcpy(&v, rec + fo.off[f], sizeof v);
       dst[size_t(f) * pitch] = T(v);
     }
+  };
+  [[maybe_unused]] constexpr size_t kLine = 64 / sizeof(T);  // records per output cache line
+  size_t j = lo;
+  const size_t end = lo + count;
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+  if (n_fields <= 16 && (reinterpret_cast<uintptr_t>(pinned) & 63u) == 0 && pitch % kLine == 0) {
+    for (; j < end && (j % kLine) != 0; ++j) one(j);  // up to the next line boundary of the image
+    alignas(64) T block[16][kLine];
+    for (; j + kLine <= end; j += kLine) {
+      for (size_t r = 0; r < kLine; ++r) {
+        const unsigned char* rec = host + (first + j + r) * stride;
+        for (int f = 0; f < n_fields; ++f) {
+          double v;
+          memcpy(&v, rec + fo.off[f], sizeof v);
+          block[f][r] = T(v);
+        }
+      }
+      T* dst = dst_of(j);  // a line never straddles a tile: tiles are multiples of 1 024 records
+      for (int f = 0; f < n_fields; ++f) {
+        const __m128d* src = reinterpret_cast<const __m128d*>(block[f]);
+        double* line = reinterpret_cast<double*>(dst + size_t(f) * pitch);
+        _mm_stream_pd(line + 0, src[0]);
+        _mm_stream_pd(line + 2, src[1]);
+        _mm_stream_pd(line + 4, src[2]);
+        _mm_stream_pd(line + 6, src[3]);
+      }
+    }
+    _mm_sfence();  // the non-temporal stores are globally visible before this thread reports the chunk packed
   }
+#endif
+  for (; j < end; ++j) one(j);
 }
 
 int ingest_host_pack(nos_ctx* ctx, nos_dataset* ds, Shard& sh, const unsigned char* host, size_t stride,
