@@ -126,7 +126,7 @@ int indexed_from_device(nos_ctx* ctx, size_t n, const double* d_points, int n_sl
   sh.bytes = n_padded * (3 * es + sizeof(int32_t) * size_t(n_slots));
   DeviceSlot& slot = ctx->slots[0];
   hipStream_t st = slot.stream;
-  DeviceBuffers tmp;
+  DeviceBuffers tmp(&slot);  // arena (pooled slabs) for the temporaries
   uint32_t *keys = nullptr, *keys_sorted = nullptr, *ids = nullptr, *perm = nullptr;
   hipError_t e = hipSetDevice(slot.device);
   if (e == hipSuccess) e = hipMalloc(&sh.data, n_padded * 3 * es);
@@ -145,8 +145,7 @@ int indexed_from_device(nos_ctx* ctx, size_t n, const double* d_points, int n_sl
     size_t tb = 0;
     void* scratch = nullptr;
     if (e == hipSuccess) e = rocprim::radix_sort_pairs(nullptr, tb, keys, keys_sorted, ids, perm, n, 0, 32, st);
-    if (e == hipSuccess) e = hipMalloc(&scratch, std::max<size_t>(tb, 16));
-    if (e == hipSuccess) tmp.ptrs.push_back(scratch);
+    if (e == hipSuccess) e = tmp.alloc_bytes(&scratch, std::max<size_t>(tb, 16));
     if (e == hipSuccess) e = rocprim::radix_sort_pairs(scratch, tb, keys, keys_sorted, ids, perm, n, 0, 32, st);
   }
   if (e == hipSuccess) {
@@ -233,7 +232,7 @@ int nos_ndt_indexed_dataset_create(nos_ctx* ctx, size_t n_points, const double* 
       if (index_planes[k][i] >= int64_t(n_voxels)) return fail(NOS_ERR_INVALID_ARGUMENT, "voxel id out of range at point %zu", i);
   }
   DeviceSlot& slot = ctx->slots[0];
-  DeviceBuffers buf;
+  DeviceBuffers buf(&slot);
   double *d_pts = nullptr, *d_means = nullptr, *d_S = nullptr;
   int32_t* d_idx = nullptr;
   hipError_t e = hipSetDevice(slot.device);
@@ -262,7 +261,7 @@ int nos_ndt_match_indexed(nos_ndt_map* map, nos_scan* scan, const double R[9], c
   if (max_neighbors < 1 || max_neighbors > 2) return fail(NOS_ERR_UNSUPPORTED, "max_neighbors must be 1 or 2");
   nos_ctx* ctx = map->ctx;
   DeviceSlot& slot = ctx->slots[0];
-  DeviceBuffers buf;
+  DeviceBuffers buf(&slot);
   int32_t* d_idx = nullptr;
   const size_t n = scan->n;
   hipError_t e = hipSetDevice(slot.device);

@@ -243,6 +243,7 @@ struct nos_ndt_map {
   unsigned long long* d_n_matches = nullptr;
   uint32_t* d_dense_begin = nullptr;  // dense grid offsets (null when the bounding box is too large)
   double* d_record = nullptr;         // [V][4] candidate records of the dense path
+  void* d_block = nullptr;            // the ONE allocation behind d_mean, d_sqrt_info, the hash table, d_dense_begin, d_record
   nos::MapView view{};
 };
 
@@ -266,17 +267,59 @@ hipError_t upload(T** dptr, const std::vector<T>& host) {
   return e;
 }
 
+int pool_alloc(DeviceSlot& slot, size_t bytes, void** ptr, size_t* capacity);
+void pool_release(DeviceSlot& slot, void* ptr, size_t capacity);
+
+// Scratch buffers of one call, freed when it returns.  Without a slot: one hipMalloc / hipFree per buffer (round 1).  With a
+// slot (round 4): an ARENA — buffers are carved out of a few large slabs that come from the slot's buffer pool and go back
+// to it, so a map build no longer pays ≈ 20 hipMalloc + hipFree pairs (each hipFree also waits for the device) per call,
+// and repeated builds of similar size pay none.  reserve() sizes the next slab when the caller knows what is coming.
 struct DeviceBuffers {
-  std::vector<void*> ptrs;
+  std::vector<void*> ptrs;  // buffers allocated one by one (and rocPRIM temporaries the callers push here)
+  struct Slab {
+    void* ptr;
+    size_t capacity, used;
+  };
+  std::vector<Slab> slabs;
+  DeviceSlot* slot = nullptr;
+  size_t next_slab = 0;
+  DeviceBuffers() = default;
+  explicit DeviceBuffers(DeviceSlot* s) : slot(s) {}
+  DeviceBuffers(const DeviceBuffers&) = delete;
+  DeviceBuffers& operator=(const DeviceBuffers&) = delete;
   ~DeviceBuffers() {
     for (void* p : ptrs)
       if (p) (void)hipFree(p);
+    if (!slabs.empty()) (void)hipStreamSynchronize(slot->stream);  // nothing in flight may still use a slab that goes back
+    for (Slab& sl : slabs) pool_release(*slot, sl.ptr, sl.capacity);
+  }
+  void reserve(size_t bytes) { next_slab = bytes; }
+  hipError_t alloc_bytes(void** out, size_t bytes) {
+    bytes = (std::max<size_t>(bytes, 1) + 255) & ~size_t(255);
+    *out = nullptr;
+    if (slot == nullptr) {
+      hipError_t e = hipMalloc(out, bytes);
+      if (e == hipSuccess) ptrs.push_back(*out);
+      return e;
+    }
+    if (slabs.empty() || slabs.back().capacity - slabs.back().used < bytes) {
+      const size_t grown = slabs.empty() ? size_t(8) << 20 : std::min<size_t>(2 * slabs.back().capacity, size_t(1) << 30);
+      const size_t want = std::max(std::max(bytes, next_slab), grown);
+      next_slab = 0;
+      void* p = nullptr;
+      size_t cap = 0;
+      if (pool_alloc(*slot, want, &p, &cap) != 0) return hipErrorOutOfMemory;
+      slabs.push_back(Slab{p, cap, 0});
+    }
+    Slab& sl = slabs.back();
+    *out = static_cast<char*>(sl.ptr) + sl.used;
+    sl.used += bytes;
+    return hipSuccess;
   }
   template <typename T>
   hipError_t alloc(T** out, size_t count) {
     void* p = nullptr;
-    hipError_t e = hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T));
-    if (e == hipSuccess) ptrs.push_back(p);
+    const hipError_t e = alloc_bytes(&p, std::max<size_t>(count, 1) * sizeof(T));
     *out = static_cast<T*>(p);
     return e;
   }

@@ -41,7 +41,7 @@ int nos_scan_sort_by_cell(nos_scan* scan, double cell_edge) {
   if (n >= 0xFFFFFFFFull) return fail(NOS_ERR_UNSUPPORTED, "too many points");
   DeviceSlot& slot = scan->ctx->slots[0];
   hipStream_t st = slot.stream;
-  DeviceBuffers buf;
+  DeviceBuffers buf(&slot);  // arena (pooled slabs) for the temporaries
   uint64_t *keys = nullptr, *keys_sorted = nullptr;
   uint32_t *idx = nullptr, *order = nullptr;
   double* sorted = nullptr;
@@ -59,8 +59,7 @@ int nos_scan_sort_by_cell(nos_scan* scan, double cell_edge) {
     size_t tmp_bytes = 0;
     void* tmp = nullptr;
     if (e == hipSuccess) e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys_sorted, idx, order, n, 0, 64, st);
-    if (e == hipSuccess) e = hipMalloc(&tmp, std::max(tmp_bytes, size_t(16)));
-    if (e == hipSuccess) buf.ptrs.push_back(tmp);
+    if (e == hipSuccess) e = buf.alloc_bytes(&tmp, std::max(tmp_bytes, size_t(16)));
     if (e == hipSuccess) e = rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys_sorted, idx, order, n, 0, 64, st);
     for (int f = 0; f < 3 && e == hipSuccess; ++f) {
       hipLaunchKernelGGL((nos::gather_plane_kernel<double, double>), grid, dim3(256), 0, st, scan->d_planes + size_t(f) * n,
@@ -151,11 +150,12 @@ int nos_ndt_map_build(nos_ctx* ctx, size_t n_points, const double* points_xyz, d
   if (rc != NOS_OK) return rc;
   DeviceSlot& slot = ctx->slots[0];
   hipStream_t st = slot.stream;
-  DeviceBuffers buf;
+  DeviceBuffers buf(&slot);  // arena: slabs from the slot's buffer pool instead of ≈ 20 hipMalloc / hipFree pairs per build
   uint64_t *keys = nullptr, *keys_sorted = nullptr, *uniq = nullptr;
   uint32_t *idx = nullptr, *idx_sorted = nullptr, *counts = nullptr, *offsets = nullptr, *n_runs = nullptr;
   hipError_t e = hipSetDevice(slot.device);
   const size_t n = n_points;
+  buf.reserve(n * (3 * sizeof(uint64_t) + 4 * sizeof(uint32_t)) + (size_t(64) << 20));  // the seven n-sized arrays + sort temporaries
   if (e == hipSuccess) e = buf.alloc(&keys, n);
   if (e == hipSuccess) e = buf.alloc(&keys_sorted, n);
   if (e == hipSuccess) e = buf.alloc(&idx, n);
@@ -177,8 +177,7 @@ int nos_ndt_map_build(nos_ctx* ctx, size_t n_points, const double* points_xyz, d
     if (e == hipSuccess) e = rocprim::radix_sort_pairs(nullptr, t1, keys, keys_sorted, idx, idx_sorted, n, 0, 64, st);
     if (e == hipSuccess) e = rocprim::run_length_encode(nullptr, t2, keys_sorted, n, uniq, counts, n_runs, st);
     if (e == hipSuccess) e = rocprim::exclusive_scan(nullptr, t3, counts, offsets, 0u, n, rocprim::plus<uint32_t>(), st);
-    if (e == hipSuccess) e = hipMalloc(&tmp, std::max(std::max(t1, t2), std::max(t3, size_t(16))));
-    if (e == hipSuccess) buf.ptrs.push_back(tmp);
+    if (e == hipSuccess) e = buf.alloc_bytes(&tmp, std::max(std::max(t1, t2), std::max(t3, size_t(16))));
     if (e == hipSuccess) e = rocprim::radix_sort_pairs(tmp, t1, keys, keys_sorted, idx, idx_sorted, n, 0, 64, st);
     if (e == hipSuccess) e = rocprim::run_length_encode(tmp, t2, keys_sorted, n, uniq, counts, n_runs, st);
     if (e == hipSuccess) e = hipMemcpyAsync(&V, n_runs, sizeof V, hipMemcpyDeviceToHost, st);
@@ -190,6 +189,7 @@ int nos_ndt_map_build(nos_ctx* ctx, size_t n_points, const double* points_xyz, d
   double *d_mean = nullptr, *d_S = nullptr, *d_acc = nullptr, *d_evals = nullptr, *d_evecs = nullptr;
   unsigned char* d_valid = nullptr;
   uint32_t* d_first = nullptr;
+  buf.reserve(size_t(V) * (3 + 9 + 12 + 3 + 9) * sizeof(double) + size_t(V) * 8 + (size_t(1) << 20));  // the V-sized arrays
   if (e == hipSuccess) e = buf.alloc(&d_mean, size_t(V) * 3);
   if (e == hipSuccess) e = buf.alloc(&d_S, size_t(V) * 9);
   if (e == hipSuccess) e = buf.alloc(&d_valid, size_t(V));

@@ -131,7 +131,8 @@ int map_create_from_device(nos_ctx* ctx, size_t n_voxels, const double* d_means,
   nos_ndt_map* map = new (std::nothrow) nos_ndt_map();
   if (!map) return fail(NOS_ERR_OUT_OF_MEMORY, "host allocation failed");
   map->ctx = ctx;
-  DeviceBuffers buf;
+  DeviceBuffers buf(&slot);  // arena (pooled slabs) for the temporaries
+  buf.reserve(std::max<size_t>(V, 1) * (3 * sizeof(uint64_t) + 3 * sizeof(uint32_t)) + (size_t(16) << 20));
   uint64_t *keys = nullptr, *keys_sorted = nullptr, *uniq = nullptr;
   uint32_t *idx = nullptr, *run_count = nullptr, *run_start = nullptr, *n_runs = nullptr;
   unsigned int *flags = nullptr, *box = nullptr;
@@ -164,8 +165,7 @@ int map_create_from_device(nos_ctx* ctx, size_t n_voxels, const double* d_means,
     if (e == hipSuccess) e = rocprim::radix_sort_pairs(nullptr, t_sort, keys, keys_sorted, idx, map->d_orig_id, size_t(V), 0, 64, st);
     if (e == hipSuccess) e = rocprim::run_length_encode(nullptr, t_rle, keys_sorted, size_t(V), uniq, run_count, n_runs, st);
     if (e == hipSuccess) e = rocprim::exclusive_scan(nullptr, t_scan, run_count, run_start, 0u, size_t(V), rocprim::plus<uint32_t>(), st);
-    if (e == hipSuccess) e = hipMalloc(&tmp, std::max(std::max(t_sort, t_rle), std::max(t_scan, size_t(16))));
-    if (e == hipSuccess) buf.ptrs.push_back(tmp);
+    if (e == hipSuccess) e = buf.alloc_bytes(&tmp, std::max(std::max(t_sort, t_rle), std::max(t_scan, size_t(16))));
     // stable: the voxels of a cell stay in index order, as std::sort on (key, index) pairs left them
     if (e == hipSuccess) e = rocprim::radix_sort_pairs(tmp, t_sort, keys, keys_sorted, idx, map->d_orig_id, size_t(V), 0, 64, st);
     if (e == hipSuccess) e = rocprim::run_length_encode(tmp, t_rle, keys_sorted, size_t(V), uniq, run_count, n_runs, st);
@@ -217,18 +217,28 @@ int map_create_from_device(nos_ctx* ctx, size_t n_voxels, const double* d_means,
   size_t table_size = 16;
   while (table_size < 2 * size_t(n_cells) + 1) table_size <<= 1;
   const size_t nv = std::max<size_t>(n_valid, 1);
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&map->d_mean), nv * 3 * sizeof(double));
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&map->d_sqrt_info), nv * 9 * sizeof(double));
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&map->d_cell_key), table_size * sizeof(uint64_t));
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&map->d_cell_start), table_size * sizeof(uint32_t));
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&map->d_cell_count), table_size * sizeof(uint32_t));
-  if (e == hipSuccess) e = hipMemsetAsync(map->d_cell_key, 0xFF, table_size * sizeof(uint64_t), st);  // kEmptyCell
-  if (e == hipSuccess) e = hipMemsetAsync(map->d_cell_start, 0, table_size * sizeof(uint32_t), st);
-  if (e == hipSuccess) e = hipMemsetAsync(map->d_cell_count, 0, table_size * sizeof(uint32_t), st);
-  if (e == hipSuccess && n_dense > 0) {
-    e = hipMalloc(reinterpret_cast<void**>(&map->d_dense_begin), (n_dense + 1) * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMemsetAsync(map->d_dense_begin, 0, (n_dense + 1) * sizeof(uint32_t), st);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&map->d_record), nv * 4 * sizeof(double));
+  // one allocation for everything the map keeps (seven arrays), one memset for the part that starts cleared
+  {
+    auto up = [](size_t b) { return (b + 255) & ~size_t(255); };
+    const size_t b_mean = up(nv * 3 * sizeof(double)), b_S = up(nv * 9 * sizeof(double));
+    const size_t b_rec = n_dense > 0 ? up(nv * 4 * sizeof(double)) : 0;
+    const size_t b_start = up(table_size * sizeof(uint32_t)), b_count = up(table_size * sizeof(uint32_t));
+    const size_t b_dense = n_dense > 0 ? up((n_dense + 1) * sizeof(uint32_t)) : 0, b_key = up(table_size * sizeof(uint64_t));
+    char* base = nullptr;
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&base), b_mean + b_S + b_rec + b_start + b_count + b_dense + b_key);
+    if (e == hipSuccess) {
+      map->d_block = base;
+      map->d_mean = reinterpret_cast<double*>(base);
+      map->d_sqrt_info = reinterpret_cast<double*>(base + b_mean);
+      if (n_dense > 0) map->d_record = reinterpret_cast<double*>(base + b_mean + b_S);
+      char* cleared = base + b_mean + b_S + b_rec;  // start, count, dense offsets: zero; keys behind them: kEmptyCell
+      map->d_cell_start = reinterpret_cast<uint32_t*>(cleared);
+      map->d_cell_count = reinterpret_cast<uint32_t*>(cleared + b_start);
+      if (n_dense > 0) map->d_dense_begin = reinterpret_cast<uint32_t*>(cleared + b_start + b_count);
+      map->d_cell_key = reinterpret_cast<uint64_t*>(cleared + b_start + b_count + b_dense);
+      e = hipMemsetAsync(cleared, 0, b_start + b_count + b_dense, st);
+      if (e == hipSuccess) e = hipMemsetAsync(map->d_cell_key, 0xFF, table_size * sizeof(uint64_t), st);
+    }
   }
   if (e == hipSuccess && n_valid > 0) {
     hipLaunchKernelGGL(map_gather_kernel, dim3((n_valid + 255) / 256), dim3(256), 0, st, d_means, d_S, map->d_orig_id, n_valid,
@@ -241,8 +251,7 @@ int map_create_from_device(nos_ctx* ctx, size_t n_voxels, const double* d_means,
       size_t t_inc = 0;
       void* tmp2 = nullptr;
       e = rocprim::inclusive_scan(nullptr, t_inc, map->d_dense_begin, map->d_dense_begin, n_dense + 1, rocprim::plus<uint32_t>(), st);
-      if (e == hipSuccess) e = hipMalloc(&tmp2, std::max<size_t>(t_inc, 16));
-      if (e == hipSuccess) buf.ptrs.push_back(tmp2);
+      if (e == hipSuccess) e = buf.alloc_bytes(&tmp2, std::max<size_t>(t_inc, 16));
       if (e == hipSuccess)
         e = rocprim::inclusive_scan(tmp2, t_inc, map->d_dense_begin, map->d_dense_begin, n_dense + 1, rocprim::plus<uint32_t>(), st);
     }
@@ -295,7 +304,7 @@ int nos_ndt_map_create(nos_ctx* ctx, size_t n_voxels, const double* means_xyz, c
   // the voxel statistics go to the device as they are; bucketing by matcher cell, the hash table and the dense grid are
   // built there (map_create_from_device)
   DeviceSlot& slot = ctx->slots[0];
-  DeviceBuffers buf;
+  DeviceBuffers buf(&slot);
   double *d_means = nullptr, *d_S = nullptr;
   unsigned char* d_valid = nullptr;
   hipError_t e = hipSetDevice(slot.device);
@@ -316,15 +325,9 @@ int nos_ndt_map_destroy(nos_ndt_map* map) {
   nosd::CtxGuard guard_(map ? map->ctx : nullptr);  // one solve / accumulate / create at a time per context
   if (!map) return NOS_OK;
   (void)hipSetDevice(map->ctx->slots[0].device);
-  if (map->d_mean) (void)hipFree(map->d_mean);
-  if (map->d_sqrt_info) (void)hipFree(map->d_sqrt_info);
+  if (map->d_block) (void)hipFree(map->d_block);  // d_mean, d_sqrt_info, the hash table, d_dense_begin, d_record
   if (map->d_orig_id) (void)hipFree(map->d_orig_id);
-  if (map->d_cell_key) (void)hipFree(map->d_cell_key);
-  if (map->d_cell_start) (void)hipFree(map->d_cell_start);
-  if (map->d_cell_count) (void)hipFree(map->d_cell_count);
   if (map->d_n_matches) (void)hipFree(map->d_n_matches);
-  if (map->d_dense_begin) (void)hipFree(map->d_dense_begin);
-  if (map->d_record) (void)hipFree(map->d_record);
   delete map;
   return NOS_OK;
 }
