@@ -41,7 +41,7 @@ def build(force=False):
     """Compile the oracle libraries with the committed Makefile (gcc only)."""
     need = force or not all(
         os.path.exists(os.path.join(_BUILD, f))
-        for f in ("libnos_oracle.so", "libnos_oracle_avx.so", "libnos_scene_oracle.so")
+        for f in ("libnos_oracle.so", "libnos_oracle_avx.so", "libnos_scene_oracle.so", "libnos_pgo_oracle.so")
     )
     if need:
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
@@ -321,3 +321,45 @@ def pack_records_f32(records, stride, field_offsets):
     if rc != 0:
         raise RuntimeError("oracle_pack_records_f32 failed: %d" % rc)
     return planes
+
+
+# ---- pose-graph linearisation in C (pgo_oracle.c; the twin of oracle_pgo.Graph.linearize)
+_pgo = None
+
+
+def pgo():
+    global _pgo
+    if _pgo is None:
+        build()
+        _pgo = ctypes.CDLL(os.path.join(_BUILD, "libnos_pgo_oracle.so"))
+        dp, ip, bp = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_ubyte)
+        _pgo.oracle_pgo_linearize.argtypes = [ctypes.c_size_t, dp, ctypes.c_size_t, ip, ip, dp, dp, bp, bp, dp, dp, dp, dp, dp]
+        _pgo.oracle_pgo_linearize.restype = ctypes.c_int
+    return _pgo
+
+
+def pgo_linearize(poses, ref, qry, meas, sw=None, sw_free=None, fixed=None):
+    """→ (hdiag [n, 21] upper triangles row-major, grad [n, 6], hs [m], gs [m], cost)."""
+    poses = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 7)
+    meas = np.ascontiguousarray(meas, dtype=np.float64).reshape(-1, 7)
+    ref = np.ascontiguousarray(ref, dtype=np.int32)
+    qry = np.ascontiguousarray(qry, dtype=np.int32)
+    n, m = poses.shape[0], ref.size
+    sw = np.ones(m) if sw is None else np.ascontiguousarray(sw, dtype=np.float64)
+    dp, ip, bp = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_ubyte)
+
+    def flags(x):
+        if x is None:
+            return None, None
+        a = np.ascontiguousarray(np.asarray(x, dtype=bool).astype(np.uint8))
+        return a, a.ctypes.data_as(bp)
+    swf, swf_p = flags(sw_free)
+    fx, fx_p = flags(fixed)
+    hdiag, grad, hs, gs = np.zeros((n, 21)), np.zeros((n, 6)), np.zeros(m), np.zeros(m)
+    cost = ctypes.c_double()
+    rc = pgo().oracle_pgo_linearize(n, poses.ctypes.data_as(dp), m, ref.ctypes.data_as(ip), qry.ctypes.data_as(ip),
+                                    meas.ctypes.data_as(dp), sw.ctypes.data_as(dp), swf_p, fx_p, hdiag.ctypes.data_as(dp),
+                                    grad.ctypes.data_as(dp), hs.ctypes.data_as(dp), gs.ctypes.data_as(dp), ctypes.byref(cost))
+    if rc != 0:
+        raise ValueError("oracle_pgo_linearize: pose index out of range")
+    return hdiag, grad, hs, gs, cost.value
