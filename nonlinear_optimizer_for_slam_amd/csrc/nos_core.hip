@@ -1852,8 +1852,8 @@ int nos_dataset_destroy(nos_dataset* ds) {
         (void)hipFree(sh.data);
       }
     }
-    if (sh.index) (void)hipFree(sh.index);
-    if (sh.table) (void)hipFree(sh.table);
+    if (sh.index && !sh.one_block) (void)hipFree(sh.index);
+    if (sh.table && !sh.one_block) (void)hipFree(sh.table);
   }
   delete ds;
   return NOS_OK;

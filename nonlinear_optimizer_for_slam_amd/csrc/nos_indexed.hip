@@ -129,9 +129,25 @@ int indexed_from_device(nos_ctx* ctx, size_t n, const double* d_points, int n_sl
   DeviceBuffers tmp(&slot);  // arena (pooled slabs) for the temporaries
   uint32_t *keys = nullptr, *keys_sorted = nullptr, *ids = nullptr, *perm = nullptr;
   hipError_t e = hipSetDevice(slot.device);
-  if (e == hipSuccess) e = hipMalloc(&sh.data, n_padded * 3 * es);
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sh.index), n_padded * sizeof(int32_t) * size_t(n_slots));
-  if (e == hipSuccess) e = hipMalloc(&sh.table, std::max<size_t>(n_voxels, 1) * 16 * es);
+  // ONE pooled allocation for the point planes, the id planes and the voxel table: scan-to-map builds such a dataset every
+  // round, and three hipMalloc / hipFree pairs per round (a hipFree waits for the device) were a tenth of the round
+  if (e == hipSuccess) {
+    auto up = [](size_t b) { return (b + 255) & ~size_t(255); };
+    const size_t b_data = up(n_padded * 3 * es), b_index = up(n_padded * sizeof(int32_t) * size_t(n_slots));
+    const size_t b_table = up(std::max<size_t>(n_voxels, 1) * 16 * es);
+    void* block = nullptr;
+    size_t cap = 0;
+    if (pool_alloc(slot, b_data + b_index + b_table, &block, &cap) != NOS_OK) {
+      e = hipErrorOutOfMemory;
+    } else {
+      sh.data = block;
+      sh.capacity = cap;
+      sh.pooled = true;
+      sh.one_block = true;
+      sh.index = reinterpret_cast<int32_t*>(static_cast<char*>(block) + b_data);
+      sh.table = static_cast<char*>(block) + b_data + b_index;
+    }
+  }
   if (e == hipSuccess && sort_by_voxel && n > 0) {
     e = tmp.alloc(&keys, n);
     if (e == hipSuccess) e = tmp.alloc(&keys_sorted, n);

@@ -214,6 +214,7 @@ struct Shard {
   // voxel-indexed datasets (kKindNdtIndexed): data = 3 point planes; plus
   int32_t* index = nullptr;   // n_slots planes of n_padded voxel ids
   void* table = nullptr;      // [n_voxels][16] voxel records
+  bool one_block = false;     // index and table live inside the (pooled) allocation behind `data`: nothing else to free
   int n_slots = 0;
   size_t n_voxels = 0;
 };
