@@ -30,6 +30,70 @@ __global__ __launch_bounds__(256) void voxel_key_kernel(const double* __restrict
   idx[i] = uint32_t(i);
 }
 
+// Compact keys (round 4).  The packed key above spends 63 bits whatever the scene's extent, and a radix sort pays for every
+// one of them: 8 passes over 10 M (key, index) pairs = 0.75 of the map build's 6.8 ms.  With the cells' bounding box known,
+// key = ((x - x0) NY + (y - y0)) NZ + (z - z0) orders the cells exactly as the packed key does — lexicographically in
+// (x, y, z) — in ceil(log2(NX NY NZ)) bits: 18 for a 100 x 100 x 10 m scene at 1 m, i.e. 3 passes.
+//   box[0..2] = min cell, box[3..5] = max cell, initialised to INT64_MAX / INT64_MIN; grid-stride so that the whole grid
+//   sends a few thousand atomics, not one per wave.
+__global__ __launch_bounds__(256) void voxel_box_kernel(const double* __restrict__ px, const double* __restrict__ py,
+                                                        const double* __restrict__ pz, uint64_t n, double inv_res,
+                                                        long long* __restrict__ box) {
+  long long lo[3] = {0x7FFFFFFFFFFFFFFFll, 0x7FFFFFFFFFFFFFFFll, 0x7FFFFFFFFFFFFFFFll};
+  long long hi[3] = {-0x7FFFFFFFFFFFFFFFll - 1, -0x7FFFFFFFFFFFFFFFll - 1, -0x7FFFFFFFFFFFFFFFll - 1};
+  for (uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += uint64_t(gridDim.x) * 256) {
+    const double c[3] = {floor(px[i] * inv_res), floor(py[i] * inv_res), floor(pz[i] * inv_res)};
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (c[k] >= -9.0e18 && c[k] <= 9.0e18) {  // finite and representable (a NaN fails both tests)
+        const long long v = (long long)c[k];
+        lo[k] = v < lo[k] ? v : lo[k];
+        hi[k] = v > hi[k] ? v : hi[k];
+      }
+  }
+  __shared__ long long s_lo[3][256], s_hi[3][256];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    s_lo[k][threadIdx.x] = lo[k];
+    s_hi[k][threadIdx.x] = hi[k];
+  }
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (int(threadIdx.x) < o) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const long long a = s_lo[k][threadIdx.x + o], b = s_hi[k][threadIdx.x + o];
+        if (a < s_lo[k][threadIdx.x]) s_lo[k][threadIdx.x] = a;
+        if (b > s_hi[k][threadIdx.x]) s_hi[k][threadIdx.x] = b;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 3) {
+    atomicMin(&box[threadIdx.x], s_lo[threadIdx.x][0]);
+    atomicMax(&box[3 + threadIdx.x], s_hi[threadIdx.x][0]);
+  }
+}
+
+// origin = min cell, dims = NX, NY, NZ (their product < 2^62); coordinates outside the box (non-finite points) are clamped in
+__global__ __launch_bounds__(256) void voxel_compact_key_kernel(const double* __restrict__ px, const double* __restrict__ py,
+                                                                const double* __restrict__ pz, uint64_t n, double inv_res,
+                                                                long long x0, long long y0, long long z0, long long nx,
+                                                                long long ny, long long nz, uint64_t* __restrict__ keys,
+                                                                uint32_t* __restrict__ idx) {
+  const uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= n) return;
+  auto rel = [](double c, long long origin, long long dim) -> long long {
+    if (!(c >= -9.0e18 && c <= 9.0e18)) return 0;
+    const long long v = (long long)c - origin;
+    return v < 0 ? 0 : (v >= dim ? dim - 1 : v);
+  };
+  const long long x = rel(floor(px[i] * inv_res), x0, nx), y = rel(floor(py[i] * inv_res), y0, ny),
+                  z = rel(floor(pz[i] * inv_res), z0, nz);
+  keys[i] = uint64_t((x * ny + y) * nz + z);
+  idx[i] = uint32_t(i);
+}
+
 // Cyclic Jacobi for a symmetric 3x3 (row-major a[9]); eigenvalues ascending in w, eigenvectors in
 // the COLUMNS of V (row-major), signs fixed as described in the file header.
 __host__ __device__ inline void symmetric_eigen3(const double* A, double* w, double* V) {

@@ -168,17 +168,52 @@ int nos_ndt_map_build(nos_ctx* ctx, size_t n_points, const double* points_xyz, d
   const double* py = scan->d_planes + n;
   const double* pz = scan->d_planes + 2 * n;
   uint32_t V = 0;
+  // compact keys: cell index inside the points' bounding box (voxel_compact_key_kernel) — same order, a third of the bits
+  long long h_box[6] = {0x7FFFFFFFFFFFFFFFll, 0x7FFFFFFFFFFFFFFFll, 0x7FFFFFFFFFFFFFFFll,
+                        -0x7FFFFFFFFFFFFFFFll - 1, -0x7FFFFFFFFFFFFFFFll - 1, -0x7FFFFFFFFFFFFFFFll - 1};
+  long long dims[3] = {1, 1, 1};
+  bool compact = false;
+  unsigned key_bits = 64;
   if (e == hipSuccess && n > 0) {
-    hipLaunchKernelGGL(nos::voxel_key_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, st, px, py, pz, uint64_t(n),
-                       1.0 / voxel_resolution, keys, idx);
+    long long* d_box = nullptr;
+    e = buf.alloc(&d_box, 6);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_box, h_box, sizeof h_box, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+      const unsigned blocks = unsigned(std::min<size_t>((n + 255) / 256, 1024));
+      hipLaunchKernelGGL(nos::voxel_box_kernel, dim3(blocks), dim3(256), 0, st, px, py, pz, uint64_t(n), 1.0 / voxel_resolution, d_box);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(h_box, d_box, sizeof h_box, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess && h_box[0] <= h_box[3] && h_box[1] <= h_box[4] && h_box[2] <= h_box[5]) {
+      double total = 1.0;
+      for (int k = 0; k < 3; ++k) {
+        const double d = double(h_box[3 + k]) - double(h_box[k]) + 1.0;
+        total *= d;
+      }
+      if (total < 4.0e18) {  // the cell index fits 62 bits
+        compact = true;
+        for (int k = 0; k < 3; ++k) dims[k] = h_box[3 + k] - h_box[k] + 1;
+        key_bits = 1;
+        while (key_bits < 64 && double(1ull << key_bits) < total) ++key_bits;
+      }
+    }
+  }
+  if (e == hipSuccess && n > 0) {
+    if (compact)
+      hipLaunchKernelGGL(nos::voxel_compact_key_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, st, px, py, pz, uint64_t(n),
+                         1.0 / voxel_resolution, h_box[0], h_box[1], h_box[2], dims[0], dims[1], dims[2], keys, idx);
+    else
+      hipLaunchKernelGGL(nos::voxel_key_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, st, px, py, pz, uint64_t(n),
+                         1.0 / voxel_resolution, keys, idx);
     e = hipGetLastError();
     size_t t1 = 0, t2 = 0, t3 = 0;
     void* tmp = nullptr;
-    if (e == hipSuccess) e = rocprim::radix_sort_pairs(nullptr, t1, keys, keys_sorted, idx, idx_sorted, n, 0, 64, st);
+    if (e == hipSuccess) e = rocprim::radix_sort_pairs(nullptr, t1, keys, keys_sorted, idx, idx_sorted, n, 0, key_bits, st);
     if (e == hipSuccess) e = rocprim::run_length_encode(nullptr, t2, keys_sorted, n, uniq, counts, n_runs, st);
     if (e == hipSuccess) e = rocprim::exclusive_scan(nullptr, t3, counts, offsets, 0u, n, rocprim::plus<uint32_t>(), st);
     if (e == hipSuccess) e = buf.alloc_bytes(&tmp, std::max(std::max(t1, t2), std::max(t3, size_t(16))));
-    if (e == hipSuccess) e = rocprim::radix_sort_pairs(tmp, t1, keys, keys_sorted, idx, idx_sorted, n, 0, 64, st);
+    if (e == hipSuccess) e = rocprim::radix_sort_pairs(tmp, t1, keys, keys_sorted, idx, idx_sorted, n, 0, key_bits, st);
     if (e == hipSuccess) e = rocprim::run_length_encode(tmp, t2, keys_sorted, n, uniq, counts, n_runs, st);
     if (e == hipSuccess) e = hipMemcpyAsync(&V, n_runs, sizeof V, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -256,9 +291,16 @@ int nos_ndt_map_build(nos_ctx* ctx, size_t n_points, const double* points_xyz, d
     return fail(e == hipErrorOutOfMemory ? NOS_ERR_OUT_OF_MEMORY : NOS_ERR_HIP, "map build failed: %s", hipGetErrorString(e));
   const int64_t bias = int64_t(1) << 20;
   for (uint32_t v = 0; v < V && want_stats; ++v) {
-    stats->cells[3 * size_t(v) + 0] = int64_t((h_keys[v] >> 42) & 0x1FFFFFull) - bias;
-    stats->cells[3 * size_t(v) + 1] = int64_t((h_keys[v] >> 21) & 0x1FFFFFull) - bias;
-    stats->cells[3 * size_t(v) + 2] = int64_t(h_keys[v] & 0x1FFFFFull) - bias;
+    if (compact) {
+      const uint64_t k = h_keys[v], nyz = uint64_t(dims[1]) * uint64_t(dims[2]);
+      stats->cells[3 * size_t(v) + 0] = int64_t(k / nyz) + h_box[0];
+      stats->cells[3 * size_t(v) + 1] = int64_t((k % nyz) / uint64_t(dims[2])) + h_box[1];
+      stats->cells[3 * size_t(v) + 2] = int64_t(k % uint64_t(dims[2])) + h_box[2];
+    } else {
+      stats->cells[3 * size_t(v) + 0] = int64_t((h_keys[v] >> 42) & 0x1FFFFFull) - bias;
+      stats->cells[3 * size_t(v) + 1] = int64_t((h_keys[v] >> 21) & 0x1FFFFFull) - bias;
+      stats->cells[3 * size_t(v) + 2] = int64_t(h_keys[v] & 0x1FFFFFull) - bias;
+    }
   }
   if (exact && V > 1) {
     // the reference's map lists its voxels as they were first seen (our restatement of its unordered_map walk): voxel
