@@ -51,16 +51,49 @@ int nos_scan_sort_by_cell(nos_scan* scan, double cell_edge) {
   if (e == hipSuccess) e = buf.alloc(&idx, n);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&order), n * sizeof(uint32_t));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sorted), n * 3 * sizeof(double));
+  // compact keys (see voxel_compact_key_kernel): the cell's index inside the scan's bounding box, same order, fewer bits
+  long long h_box[6] = {0x7FFFFFFFFFFFFFFFll, 0x7FFFFFFFFFFFFFFFll, 0x7FFFFFFFFFFFFFFFll,
+                        -0x7FFFFFFFFFFFFFFFll - 1, -0x7FFFFFFFFFFFFFFFll - 1, -0x7FFFFFFFFFFFFFFFll - 1};
+  long long dims[3] = {1, 1, 1};
+  bool compact = false;
+  unsigned key_bits = 64;
+  if (e == hipSuccess) {
+    long long* d_box = nullptr;
+    e = buf.alloc(&d_box, 6);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_box, h_box, sizeof h_box, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(nos::voxel_box_kernel, dim3(unsigned(std::min<size_t>((n + 255) / 256, 1024))), dim3(256), 0, st,
+                         scan->d_planes, scan->d_planes + n, scan->d_planes + 2 * n, uint64_t(n), 1.0 / cell_edge, d_box);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(h_box, d_box, sizeof h_box, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess && h_box[0] <= h_box[3] && h_box[1] <= h_box[4] && h_box[2] <= h_box[5]) {
+      double total = 1.0;
+      for (int k = 0; k < 3; ++k) total *= double(h_box[3 + k]) - double(h_box[k]) + 1.0;
+      if (total < 4.0e18) {
+        compact = true;
+        for (int k = 0; k < 3; ++k) dims[k] = h_box[3 + k] - h_box[k] + 1;
+        key_bits = 1;
+        while (key_bits < 64 && double(1ull << key_bits) < total) ++key_bits;
+      }
+    }
+  }
   if (e == hipSuccess) {
     const dim3 grid(unsigned((n + 255) / 256));
-    hipLaunchKernelGGL(nos::voxel_key_kernel, grid, dim3(256), 0, st, scan->d_planes, scan->d_planes + n,
-                       scan->d_planes + 2 * n, uint64_t(n), 1.0 / cell_edge, keys, idx);
+    if (compact)
+      hipLaunchKernelGGL(nos::voxel_compact_key_kernel, grid, dim3(256), 0, st, scan->d_planes, scan->d_planes + n,
+                         scan->d_planes + 2 * n, uint64_t(n), 1.0 / cell_edge, h_box[0], h_box[1], h_box[2], dims[0], dims[1],
+                         dims[2], keys, idx);
+    else
+      hipLaunchKernelGGL(nos::voxel_key_kernel, grid, dim3(256), 0, st, scan->d_planes, scan->d_planes + n,
+                         scan->d_planes + 2 * n, uint64_t(n), 1.0 / cell_edge, keys, idx);
     e = hipGetLastError();
     size_t tmp_bytes = 0;
     void* tmp = nullptr;
-    if (e == hipSuccess) e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys_sorted, idx, order, n, 0, 64, st);
+    if (e == hipSuccess) e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys_sorted, idx, order, n, 0, key_bits, st);
     if (e == hipSuccess) e = buf.alloc_bytes(&tmp, std::max(tmp_bytes, size_t(16)));
-    if (e == hipSuccess) e = rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys_sorted, idx, order, n, 0, 64, st);
+    if (e == hipSuccess) e = rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys_sorted, idx, order, n, 0, key_bits, st);
     for (int f = 0; f < 3 && e == hipSuccess; ++f) {
       hipLaunchKernelGGL((nos::gather_plane_kernel<double, double>), grid, dim3(256), 0, st, scan->d_planes + size_t(f) * n,
                          order, uint64_t(n), uint64_t(n), 0.0, sorted + size_t(f) * n);
