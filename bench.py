@@ -597,6 +597,7 @@ def main():
                 ctx.comm_destroy()
             return None
 
+        failed_legs = {}
         for candidate in order:
             up = bring_up(candidate)
             if up is None:
@@ -607,15 +608,31 @@ def main():
             keep = ctx.get_option("lm_cluster")
             if candidate == "mailbox_device":
                 ctx.set_option("lm_cluster", 0)
+            # A leg that fails on this rank (a peer that never arrives: every in-launch wait is bounded and ends in an error)
+            # must not take the whole line with it: the ranks vote, a leg counts only if it finished on ALL of them, and the
+            # next candidate starts from a fresh communicator.
+            leg, failure = None, ""
             try:
-                legs[candidate] = run_trains(it, bracket=(candidate.startswith("mailbox") and args.loop == "device"))
+                leg = run_trains(it, bracket=(candidate.startswith("mailbox") and args.loop == "device"))
+            except Exception as exc:  # noqa: BLE001
+                failure = "%s: %s" % (type(exc).__name__, exc)
+                print("[bench] leg %s failed on rank %d: %s" % (candidate, rank, failure), file=sys.stderr)
             finally:
                 ctx.set_option("lm_cluster", keep)
-            legs[candidate].update(up)
-            legs[candidate]["launches_per_train"] = getattr(work, "launches_of_last_solve", None)
+            try:
+                ctx.comm_destroy()
+            except Exception:  # noqa: BLE001
+                pass
+            vote = torch.tensor([1.0 if leg is not None else 0.0], dtype=torch.float64)
+            dist.all_reduce(vote, op=dist.ReduceOp.MIN)
+            if float(vote[0].item()) < 0.5:
+                failed_legs[candidate] = failure or "failed on another rank"
+                continue
+            leg.update(up)
+            leg["launches_per_train"] = getattr(work, "launches_of_last_solve", None)
             if candidate == "rccl-native":
-                legs[candidate]["ncclCommCount"] = up["ranks_seen"]
-            ctx.comm_destroy()
+                leg["ncclCommCount"] = up["ranks_seen"]
+            legs[candidate] = leg
         mailboxes = [c for c in legs if c.startswith("mailbox")]
         if "rccl-native" in legs:
             comm_mode = "rccl-native"
@@ -646,6 +663,8 @@ def main():
                             "ranks_seen": v.get("ranks_seen"), "ncclCommCount": v.get("ncclCommCount"),
                             "launches_per_train": v.get("launches_per_train")}
                         for k, v in legs.items() if k != "main"}
+        for k, why in failed_legs.items():
+            comm_details[k] = {"failed": why}
 
     main_leg = legs["main"]
     launched_kernel = ctx.last_kernel()  # the instantiation the library chose for the timed trains, by its symbol
