@@ -1511,6 +1511,7 @@ int nos_ctx_create(const int* device_ids, int n_devices, nos_ctx** out_ctx) {
     st.ingest_threads = env_int("NOS_INGEST_THREADS", 0);
     st.indexed_bpc = env_int("NOS_INDEXED_BPC", st.indexed_bpc);
     st.match_dense = env_int("NOS_MATCH_DENSE", st.match_dense);
+    st.map_compact_keys = env_int("NOS_MAP_COMPACT_KEYS", st.map_compact_keys);
     st.pgo_host_scalars = env_int("NOS_PGO_HOST_SCALARS", st.pgo_host_scalars);
     st.pgo_precond = env_int("NOS_PGO_PRECOND", st.pgo_precond);
     st.pgo_agg = env_int("NOS_PGO_AGG", st.pgo_agg);
@@ -1681,6 +1682,7 @@ const OptionEntry kOptions[] = {
     {"ingest_threads", &nosd::Settings::ingest_threads, 0, 1024},
     {"indexed_bpc", &nosd::Settings::indexed_bpc, 1, 16},
     {"match_dense", &nosd::Settings::match_dense, 0, 1},
+    {"map_compact_keys", &nosd::Settings::map_compact_keys, 0, 1},
     {"pgo_host_scalars", &nosd::Settings::pgo_host_scalars, 0, 1},
     {"pgo_precond", &nosd::Settings::pgo_precond, 0, 1},
     {"pgo_agg", &nosd::Settings::pgo_agg, 2, 1 << 20},

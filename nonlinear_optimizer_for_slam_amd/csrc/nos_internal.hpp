@@ -152,6 +152,7 @@ struct Settings {
   int ingest_threads = 0;    // NOS_INGEST_THREADS  0 = min(16, hw / 2)
   int indexed_bpc = 1;       // NOS_INDEXED_BPC
   int match_dense = 1;       // NOS_MATCH_DENSE
+  int map_compact_keys = 1;  // NOS_MAP_COMPACT_KEYS  sort voxels / scan cells by their index inside the bounding box (0: 63-bit packed keys)
   int pgo_host_scalars = 0;  // NOS_PGO_HOST_SCALARS
   int pgo_precond = 1;       // NOS_PGO_PRECOND     0 block-Jacobi only, 1 two-level (rigid-motion coarse space)
   int pgo_agg = 48;          // NOS_PGO_AGG         poses per aggregate of the coarse level

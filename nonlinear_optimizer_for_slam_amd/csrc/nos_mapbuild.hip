@@ -68,7 +68,7 @@ int nos_scan_sort_by_cell(nos_scan* scan, double cell_edge) {
     }
     if (e == hipSuccess) e = hipMemcpyAsync(h_box, d_box, sizeof h_box, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e == hipSuccess && h_box[0] <= h_box[3] && h_box[1] <= h_box[4] && h_box[2] <= h_box[5]) {
+    if (e == hipSuccess && scan->ctx->settings.map_compact_keys != 0 && h_box[0] <= h_box[3] && h_box[1] <= h_box[4] && h_box[2] <= h_box[5]) {
       double total = 1.0;
       for (int k = 0; k < 3; ++k) total *= double(h_box[3 + k]) - double(h_box[k]) + 1.0;
       if (total < 4.0e18) {
@@ -218,7 +218,7 @@ int nos_ndt_map_build(nos_ctx* ctx, size_t n_points, const double* points_xyz, d
     }
     if (e == hipSuccess) e = hipMemcpyAsync(h_box, d_box, sizeof h_box, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e == hipSuccess && h_box[0] <= h_box[3] && h_box[1] <= h_box[4] && h_box[2] <= h_box[5]) {
+    if (e == hipSuccess && ctx->settings.map_compact_keys != 0 && h_box[0] <= h_box[3] && h_box[1] <= h_box[4] && h_box[2] <= h_box[5]) {
       double total = 1.0;
       for (int k = 0; k < 3; ++k) {
         const double d = double(h_box[3 + k]) - double(h_box[k]) + 1.0;

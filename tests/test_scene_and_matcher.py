@@ -248,6 +248,34 @@ def test_gpu_map_build_edge_cases(ctx):
 
 
 @pytest.mark.gpu
+def test_compact_sort_keys_give_the_same_map_and_the_same_scan_order_as_packed_keys(ctx):
+    """Round 4: voxels (map build) and scan cells (nos_scan_sort_by_cell) are sorted by their index INSIDE THE BOUNDING BOX
+    (three radix passes) instead of by the 63-bit packed cell (eight).  Same lexicographic (x, y, z) order, stable sort →
+    the same voxel list with the same statistics bit for bit, negative coordinates and a far-away outlier included, and the
+    same scan permutation; `map_compact_keys = 0` is the packed form."""
+    from nonlinear_optimizer_for_slam_amd import api
+    rng = np.random.default_rng(20261005)
+    pts = np.concatenate([rng.uniform([-37, -12, -4], [41, 29, 6], size=(200_000, 3)),
+                          rng.uniform(0, 1, size=(300, 3)) + np.array([-900.0, 1500.0, 77.0])])   # stretches the box
+    rng.shuffle(pts)
+    out = {}
+    for compact in (1, 0):
+        with ctx.options(map_compact_keys=compact):
+            gm, st = api.NdtMap.build(ctx, pts, 1.0, 1.0)
+            sc = api.Scan(ctx, pts, sort_cell=0.8)
+            out[compact] = (st, sc.order.copy(), len(gm))
+            sc.close()
+            gm.close()
+    a, b = out[1], out[0]
+    assert a[2] == b[2] and a[2] > 1000
+    for key in ("cells", "counts", "valid", "means", "sqrt_infos"):
+        assert np.array_equal(a[0][key], b[0][key]), key
+    assert np.array_equal(a[1], b[1])
+    cells = a[0]["cells"]
+    assert np.all(np.lexsort((cells[:, 2], cells[:, 1], cells[:, 0])) == np.arange(len(cells)))  # lexicographic (x, y, z)
+
+
+@pytest.mark.gpu
 def test_cell_sorted_scan_gives_the_same_matches_in_permuted_order(ctx):
     """nos_scan_sort_by_cell only changes the order of the points (and therefore of the output slots): slot pair j of
     the sorted scan equals slot pair order[j] of the unsorted one, bit for bit; sorting twice composes the orders."""
