@@ -191,10 +191,24 @@ struct MapBuildParams {
 // idled: at 796 k voxels of ≈ 12 points that was 3.0 of the build's 12 ms (profiles/r04_mapbuild_summary.json: issue stalls
 // 46 %, one launch 3 041 µs).  Same additions in the same order, same eigen routine.
 //
+// The points once more as 32-byte records {x, y, z, 0}: the sums kernel GATHERS points by sorted index, and a gather of three
+// 8-byte values from three planes touches three 64-byte sectors per point (1.9 GB of HBM traffic for 10 M points, 0.9 ms:
+// profiles/r04_mapbuild_summary.json), one aligned 32-byte record one.
+__global__ __launch_bounds__(256) void points_to_records_kernel(const double* __restrict__ px, const double* __restrict__ py,
+                                                                const double* __restrict__ pz, uint64_t n,
+                                                                double* __restrict__ rec /* [n][4] */) {
+  const uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= n) return;
+  using V2 = double __attribute__((ext_vector_type(2)));
+  V2* out = reinterpret_cast<V2*>(rec) + 2 * i;
+  out[0] = V2{px[i], py[i]};
+  out[1] = V2{pz[i], 0.0};
+}
+
 // (1) One wave per voxel: count / sum / moment in a fixed order.  seg_offset[v] .. + seg_count[v] index into sorted_idx.
-//     acc_out: [n_voxels][9] = sx sy sz | mxx mxy mxz myy myz mzz.
+//     acc_out: [n_voxels][9] = sx sy sz | mxx mxy mxz myy myz mzz.  rec != nullptr: the points as records (above).
 __global__ __launch_bounds__(256) void voxel_sums_kernel(const double* __restrict__ px, const double* __restrict__ py,
-                                                         const double* __restrict__ pz,
+                                                         const double* __restrict__ pz, const double* __restrict__ rec,
                                                          const uint32_t* __restrict__ sorted_idx,
                                                          const uint32_t* __restrict__ seg_offset,
                                                          const uint32_t* __restrict__ seg_count, uint32_t n_voxels,
@@ -206,7 +220,15 @@ __global__ __launch_bounds__(256) void voxel_sums_kernel(const double* __restric
   double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (uint32_t k = lane; k < count; k += kWave) {
     const uint32_t i = sorted_idx[begin + k];
-    const double x = px[i], y = py[i], z = pz[i];
+    double x, y, z;
+    if (rec != nullptr) {  // kernel-uniform
+      using V2 = double __attribute__((ext_vector_type(2)));
+      const V2* r2 = reinterpret_cast<const V2*>(rec) + 2 * size_t(i);
+      const V2 a = r2[0], b = r2[1];
+      x = a[0], y = a[1], z = b[0];
+    } else {
+      x = px[i], y = py[i], z = pz[i];
+    }
     acc[0] += x;
     acc[1] += y;
     acc[2] += z;

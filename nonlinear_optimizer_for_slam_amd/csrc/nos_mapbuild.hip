@@ -273,8 +273,16 @@ int nos_ndt_map_build(nos_ctx* ctx, size_t n_points, const double* points_xyz, d
     const nos::MapBuildParams prm{5, 0.01, 0.01, (flags & NOS_MAP_PROPER_SQRT_INFORMATION) ? 1 : 0};
     e = buf.alloc(&d_acc, size_t(V) * 9);
     if (e == hipSuccess) {
+      // the points as 32-byte records for the gather (one sector per point instead of three); without room for them: planes
+      double* d_rec = nullptr;
+      if (n >= (size_t(1) << 16) && buf.alloc(&d_rec, n * 4) == hipSuccess) {
+        hipLaunchKernelGGL(nos::points_to_records_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, st, px, py, pz, uint64_t(n),
+                           d_rec);
+      } else {
+        d_rec = nullptr;
+      }
       const unsigned blocks = unsigned((size_t(V) * nos::kWave + 255) / 256);
-      hipLaunchKernelGGL(nos::voxel_sums_kernel, dim3(blocks), dim3(256), 0, st, px, py, pz, idx_sorted, offsets, counts, V,
+      hipLaunchKernelGGL(nos::voxel_sums_kernel, dim3(blocks), dim3(256), 0, st, px, py, pz, d_rec, idx_sorted, offsets, counts, V,
                          d_acc);
       hipLaunchKernelGGL(nos::voxel_eigen_kernel, dim3(unsigned((size_t(V) + 255) / 256)), dim3(256), 0, st, d_acc, counts, V,
                          prm, d_mean, d_S, d_valid);
